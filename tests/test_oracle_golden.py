@@ -1,0 +1,134 @@
+"""The CPU oracle (oracle/ecm_oracle.py) against golden vectors produced by the reference's own code
+(tools/make_golden.py).  Pins the oracle before anything is compared with it."""
+import torch
+
+from conftest import load_golden
+from oracle import ecm_oracle as O
+from oracle.weights import seeded
+
+torch.set_num_threads(8)
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+def test_g1_cost_volume_exact():
+    for tag, (B, C, h, w, D) in {"a": (1, 4, 5, 12, 6), "b": (2, 8, 4, 24, 20)}.items():
+        g = load_golden(f"g1{tag}_costvol")
+        L, R = seeded(f"g1{tag}.L", B, C, h, w), seeded(f"g1{tag}.R", B, C, h, w)
+        assert torch.equal(O.cost_volume(L, R, D), g["cost"])
+        assert torch.equal(torch.cat([O.matchshifted(L, R, d) for d in range(D)], 2), g["cost"])
+
+
+def test_g2_tables():
+    g = load_golden("g2_tables")
+    for i, t in enumerate(O.offset_tables(4)):
+        assert torch.equal(t, g[f"t{i}"]), i
+
+
+def test_g2_ecm_weights(cmfsm_sd):
+    g = load_golden("g2_ecm_weights")
+    sd = {k: v.clone().requires_grad_() for k, v in cmfsm_sd.items() if k.startswith("mapping_matrix")}
+    lr = seeded("g2.lr", 1, 32, 3, 4).requires_grad_()
+    hr = seeded("g2.hr", 1, 32, 12, 16).requires_grad_()
+    w9 = O.ecm_weights_eight(lr, hr, sd)
+    close(w9, g["w9"], 1e-5, 1e-6)
+    (w9 * seeded("g2.G", 1, 9, 12, 16)).sum().backward()
+    close(lr.grad, g["g_lr"])
+    close(hr.grad, g["g_hr"])
+    for i in range(4):
+        close(sd[f"mapping_matrix.similarity1.conv{i}.weight"].grad, g[f"g_similarity1_conv{i}_weight"])
+
+
+def test_g4_softargmin():
+    g = load_golden("g4_softargmin")
+    cost = seeded("g4.cost", 2, 48, 6, 10, scale=2.0).requires_grad_()
+    d = O.soft_argmin(cost)
+    close(d, g["disp"], 1e-6, 1e-5)
+    (d * seeded("g4.G", 2, 6, 10)).sum().backward()
+    close(cost.grad, g["g_cost"], 1e-5, 1e-6)
+
+
+def test_g6_hourglass(cmfsm_sd):
+    g = load_golden("g6_hourglass")
+    sd = {k: v.clone().requires_grad_() for k, v in cmfsm_sd.items() if k.startswith("dres3.")}
+    x = seeded("g6.x", 1, 32, 8, 8, 8).requires_grad_()
+    pre_in = seeded("g6.pre", 1, 64, 4, 4, 4).requires_grad_()
+    post_in = seeded("g6.post", 1, 64, 4, 4, 4).requires_grad_()
+    Go, Gp, Gq = seeded("g6.Go", 1, 32, 8, 8, 8), seeded("g6.Gp", 1, 64, 4, 4, 4), seeded("g6.Gq", 1, 64, 4, 4, 4)
+    for tag, (pi, qi) in {"none": (None, None), "both": (pre_in, post_in)}.items():
+        for t in list(sd.values()) + [x, pre_in, post_in]:
+            t.grad = None
+        out, pre, post = O.hourglass(x, pi, qi, sd, "dres3")
+        close(out, g[f"{tag}_out"]); close(pre, g[f"{tag}_pre"]); close(post, g[f"{tag}_post"])
+        ((out * Go).sum() + (pre * Gp).sum() + (post * Gq).sum()).backward()
+        close(x.grad, g[f"{tag}_gx"], 1e-3, 1e-4)
+        if pi is not None:
+            close(pre_in.grad, g[f"{tag}_gpre"], 1e-3, 1e-4)
+            close(post_in.grad, g[f"{tag}_gpost"], 1e-3, 1e-4)
+        for k in ("conv1.0.0.weight", "conv1.0.1.bias", "conv5.0.weight", "conv6.0.weight", "conv4.0.0.weight"):
+            close(sd["dres3." + k].grad, g[f"{tag}_g_{k.replace('.', '_')}"], 1e-3, 1e-4)
+
+
+def test_g6_dres_classif(cmfsm_sd):
+    g = load_golden("g6_dres_classif")
+    x64 = seeded("g6.x64", 1, 64, 8, 8, 12)
+    y0 = O.dres0(x64, cmfsm_sd)
+    y1 = O.dres1(y0, cmfsm_sd) + y0
+    yc = O.classif(y1, cmfsm_sd, "classif2")
+    close(y0, g["dres0"]); close(y1, g["dres1"]); close(yc, g["classif2"])
+
+
+def _tiny(tag, B, h, w):
+    return (seeded(f"g7{tag}.lr_l", B, 32, h, w), seeded(f"g7{tag}.hr_l", B, 32, 4 * h, 4 * w),
+            seeded(f"g7{tag}.lr_r", B, 32, h, w))
+
+
+def test_g7_hot_path_tiny(cmfsm_sd):
+    g = load_golden("g7a_hotpath")
+    lr_l, hr_l, lr_r = (t.requires_grad_() for t in _tiny("a", 1, 8, 12))
+    sd = {k: v.clone().requires_grad_() for k, v in cmfsm_sd.items() if not k.startswith("feature_extraction")}
+    assert torch.equal(O.cost_volume(lr_l, lr_r, 48).detach(), load_golden("g7a_cost")["cost"])
+    close(O.ecm_weights_eight(lr_l, hr_l, sd).detach(), g["cap_w9"], 1e-5, 1e-6)
+    preds = O.hot_path(lr_l, hr_l, lr_r, sd)
+    for i, p in enumerate(preds, 1):
+        close(p, g[f"pred{i}"], 1e-4, 1e-4)
+    loss = sum((p * seeded(f"g7a.G{i}", 1, 1, 32, 48)).sum() for i, p in enumerate(preds, 1))
+    loss.backward()
+    close(lr_l.grad, g["g_lr_l"], 2e-3, 2e-4)
+    close(hr_l.grad, g["g_hr_l"], 2e-3, 2e-4)
+    close(lr_r.grad, g["g_lr_r"], 2e-3, 2e-4)
+    for k, v in sd.items():
+        kk = k.replace(".", "_")
+        gn = v.grad.norm() if v.grad is not None else torch.zeros(())
+        close(gn, g["gn_" + kk], 2e-3, 1e-5)
+        if "g_" + kk in g:
+            close(v.grad, g["g_" + kk], 5e-3, 5e-4 * float(g["gn_" + kk]) / max(1.0, v.numel() ** 0.5) + 1e-5)
+
+
+def test_g7_q1_batch2_diagonal(cmfsm_sd):
+    """Quirk Q1: the reference returns [B,B,H,W] for B>1; the oracle returns its diagonal."""
+    g = load_golden("g7q1_hotpath")
+    assert list(g["raw_shape"]) == [2, 2, 16, 32]
+    lr_l, hr_l, lr_r = _tiny("q1", 2, 4, 8)
+    with torch.no_grad():
+        preds = O.hot_path(lr_l, hr_l, lr_r, cmfsm_sd)
+    for i, p in enumerate(preds, 1):
+        close(p, g[f"pred{i}"], 1e-4, 1e-4)
+
+
+def test_g8_full_model(cmfsm_sd):
+    g = load_golden("g8_full_cmfsm_256x512")
+    left, right = seeded("g8.left", 1, 3, 256, 512), seeded("g8.right", 1, 3, 256, 512)
+    with torch.no_grad():
+        lr_l, _, hr_l = O.feature_extraction(left, cmfsm_sd)
+        close(lr_l[..., ::4, ::4], g["fe_lr"], 1e-3, 1e-4)
+        close(hr_l[..., ::8, ::8], g["fe_hr"], 1e-3, 1e-4)
+        o = O.cmfsm_forward(left, right, cmfsm_sd)
+        gt = torch.rand(1, 256, 512, generator=torch.Generator().manual_seed(8)) * 191.0
+        # stated end-to-end tolerance: max-abs <= 2e-2 px, mean-abs <= 1e-3 px
+        for i, name in enumerate(("o1", "o2", "o3")):
+            d = (o[i][..., ::4, ::4] - g[name]).abs()
+            assert d.max() <= 2e-2 and d.mean() <= 1e-3, (name, d.max(), d.mean())
+        close(O.train_loss(o, gt), g["loss"], 1e-4, 1e-4)

@@ -1,0 +1,84 @@
+"""ctypes binding of libecm_hip.so (the C ABI declared in include/ecm_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  Prototypes below mirror include/ecm_hip.h one to one (checked by tests/test_abi.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libecm_hip.so")
+
+_P, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+# name -> (restype, argtypes); the single source of truth for the Python side of the ABI
+PROTOTYPES = {
+    "ecm_abi_version": (_I, []),
+    "ecm_error_string": (C.c_char_p, [_I]),
+    "ecm_costvol_concat_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ecm_costvol_concat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ecm_softargmin_heads_fwd": (_I, [_P, _LL, _P, _I, _I, _I, _I, _P]),
+    "ecm_softargmin_heads_bwd": (_I, [_P, _LL, _P, _P, _I, _I, _I, _I, _P]),
+    "ecm_disparity_regression_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ecm_aggregate9_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ecm_aggregate9_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ecm_weights9_scratch_bytes": (_LL, [_I, _I, _I]),
+    "ecm_weights9_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
+    "ecm_weights9_bwd_scratch_bytes": (_LL, [_I, _I, _I, _I]),
+    "ecm_weights9_bwd": (_I, [_P] * 11 + [_P, _LL, _I, _I, _I, _I, _P]),
+    "ecm_conv3d_packed_floats": (_LL, [_I, _I]),
+    "ecm_conv3d_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ecm_conv3d_k3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ecm_deconv3d_pack_weight": (_I, [_P, _P, _I, _I, _P]),
+    "ecm_deconv3d_k3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ecm_conv3d_wgrad_scratch_bytes": (_LL, [_I, _I, _I, _I, _I, _I, _I]),
+    "ecm_conv3d_k3_wgrad": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ecm_gn3d_scratch_bytes": (_LL, [_I, _I, _LL]),
+    "ecm_gn3d_stats": (_I, [_P, _P, _P, _LL, _I, _I, _LL, _F, _P]),
+    "ecm_gn3d_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _LL, _I, _P]),
+    "ecm_gn3d_bwd": (_I, [_P] * 10 + [_LL, _I, _I, _LL, _I, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libecm_hip.so once; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C explicit-context-mapping-for-stereo-matching_amd/csrc`). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name, None)
+            if fn is None:
+                continue            # reported by missing_symbols()/tests; calling it raises below
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def missing_symbols():
+    lib = load()
+    return [n for n in PROTOTYPES if not hasattr(lib, n)]
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point and raise RuntimeError on a non-zero code."""
+    lib = load()
+    fn = getattr(lib, name, None)
+    if fn is None:
+        raise RuntimeError(f"libecm_hip.so does not export {name}")
+    rc = fn(*args)
+    if rc != 0:
+        msg = lib.ecm_error_string(rc)
+        raise RuntimeError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def query(name: str, *args):
+    """Call a value-returning entry point (sizes)."""
+    return getattr(load(), name)(*args)

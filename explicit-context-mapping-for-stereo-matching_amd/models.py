@@ -1,0 +1,299 @@
+"""Drop-in mirror of the reference's `cmf.models` interface for the accelerated path.
+
+Same class names, constructor signatures, attribute tree (=> identical `state_dict()` keys/shapes, so
+reference checkpoints load), same `forward` signatures and return shapes as
+`cmf/models/cmfsm.py` -- but every hot-path stage (cost volume, 3-D aggregation, soft-argmin, ECM
+weights, ECM aggregation) runs on the gfx950 kernels in `ops.py`.  The 2-D encoder stays on
+PyTorch-ROCm (MIOpen), as BASELINE.json's north_star prescribes.
+
+Deliberate deviations (documented in DESIGN.md):
+  * device-agnostic construction (no `.cuda()` inside modules, cf. cmfsm.py:98,117,427,671);
+  * batch > 1 returns [B,1,H,W] (the reference broadcasts to [B,B,H,W], quirk Q1, cmfsm.py:714);
+  * odd hr/lr scale raises ValueError instead of `exit()` (cmfsm.py:448-449);
+  * the per-forward debug print + host sync (cmfsm.py:581-583) is dropped.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+NUM_GROUPS = 32  # cmfsm.py:31-33
+
+
+# ------------------------------------------------------------------------------------------------
+# leaf layers: nn.Conv3d / nn.ConvTranspose3d / nn.GroupNorm subclasses so parameter names, shapes and
+# layouts are exactly the reference's, with forward() on the HIP kernels.
+# ------------------------------------------------------------------------------------------------
+class HipConv3d(nn.Conv3d):
+    def forward(self, x):
+        return ops.conv3d_k3(x, self.weight, self.stride[0])
+
+
+class HipConvTranspose3d(nn.ConvTranspose3d):
+    def forward(self, x):
+        return ops.deconv3d_k3s2(x, self.weight)
+
+
+class HipGroupNorm(nn.GroupNorm):
+    """GroupNorm(32, C) on 5-D volumes; `fused()` adds the residual/ReLU the reference applies right after."""
+
+    def forward(self, x):
+        return ops.group_norm_act(x, self.weight, self.bias, None, False)
+
+    def fused(self, x, skip=None, relu=False):
+        return ops.group_norm_act(x, self.weight, self.bias, skip, relu)
+
+
+class HipReLU(nn.ReLU):
+    """Placeholder keeping the reference's Sequential indices; fused into the preceding GroupNorm kernel."""
+
+
+def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
+    """2-D conv + GroupNorm of the encoder (cmfsm.py:36-46); stays on PyTorch-ROCm."""
+    return nn.Sequential(
+        nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
+                  padding=dilation if dilation > 1 else pad, dilation=dilation, bias=False),
+        nn.GroupNorm(NUM_GROUPS, out_planes))
+
+
+def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
+    """cmfsm.py:49-58: Sequential(Conv3d(bias=False), GroupNorm(32))."""
+    if kernel_size != 3 or pad != 1:
+        raise ValueError("the HIP path implements the reference's only configuration: kernel 3, pad 1")
+    return nn.Sequential(
+        HipConv3d(in_planes, out_planes, kernel_size=3, padding=1, stride=stride, bias=False),
+        HipGroupNorm(NUM_GROUPS, out_planes))
+
+
+def _cbn(seq, x, skip=None, relu=False):
+    """Run a convbn_3d Sequential with the trailing residual/ReLU fused into the GroupNorm kernel."""
+    return seq[1].fused(seq[0](x), skip, relu)
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder (cmfsm.py:61-85, 126-236) -- plain PyTorch
+# ------------------------------------------------------------------------------------------------
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride, downsample, pad, dilation):
+        super().__init__()
+        self.conv1 = nn.Sequential(convbn(inplanes, planes, 3, stride, pad, dilation), nn.ReLU(inplace=True))
+        self.conv2 = convbn(planes, planes, 3, 1, pad, dilation)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.conv2(self.conv1(x))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return out + x
+
+
+class feature_extraction(nn.Module):
+    """Returns (1/4-res 32-ch feature, 1/2-res layer1 output, full-res 32-ch firstconv output)."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 32
+        self.firstconv = nn.Sequential(
+            convbn(3, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
+            convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
+            convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
+            nn.Conv2d(32, 32, kernel_size=3, padding=1, stride=1, bias=False))
+        self.secondconv = nn.Sequential(
+            nn.GroupNorm(NUM_GROUPS, 32), nn.ReLU(inplace=True),
+            convbn(32, 32, 3, 2, 1, 1), nn.ReLU(inplace=True),
+            convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True))
+        self.layer1 = self._make_layer(BasicBlock, 32, 3, 1, 1, 1)
+        self.layer2 = self._make_layer(BasicBlock, 64, 16, 2, 1, 1)
+        self.layer3 = self._make_layer(BasicBlock, 128, 3, 1, 1, 1)
+        self.layer4 = self._make_layer(BasicBlock, 128, 3, 1, 1, 2)
+        for i, pool in enumerate((64, 32, 16, 8), 1):
+            setattr(self, f"branch{i}", nn.Sequential(
+                nn.AvgPool2d((pool, pool), stride=(pool, pool)), convbn(128, 32, 1, 1, 0, 1), nn.ReLU(inplace=True)))
+        self.lastconv = nn.Sequential(
+            convbn(320, 128, 3, 1, 1, 1), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 32, kernel_size=1, padding=0, stride=1, bias=False))
+
+    def _make_layer(self, block, planes, blocks, stride, pad, dilation):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                nn.GroupNorm(NUM_GROUPS, planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample, pad, dilation)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        output_all = self.firstconv(x)
+        output_rt = self.layer1(self.secondconv(output_all))
+        output_raw = self.layer2(output_rt)
+        output_skip = self.layer4(self.layer3(output_raw))
+        size = output_skip.shape[-2:]
+        pyramid = [F.interpolate(getattr(self, f"branch{i}")(output_skip), size, mode="bilinear", align_corners=False)
+                   for i in (4, 3, 2, 1)]
+        feature = self.lastconv(torch.cat([output_raw, output_skip] + pyramid, 1))
+        return feature, output_rt, output_all
+
+
+# ------------------------------------------------------------------------------------------------
+# hot-path modules
+# ------------------------------------------------------------------------------------------------
+class matchshifted(nn.Module):
+    """One disparity slice of the cost volume, [B,2C,1,H,W] (cmfsm.py:88-108; unused by the reference's forward)."""
+
+    def forward(self, left, right, shift):
+        return ops.cost_volume(left, right, shift + 1)[:, :, shift:shift + 1]
+
+
+class disparityregression(nn.Module):
+    """sum_d x[:,d]*d (cmfsm.py:111-123)."""
+
+    def __init__(self, maxdisp):
+        super().__init__()
+        self.maxdisp = maxdisp
+
+    def forward(self, x):
+        return ops.disparity_regression(x)
+
+
+class hourglass(nn.Module):
+    """cmfsm.py:240-303."""
+
+    def __init__(self, inplanes):
+        super().__init__()
+        c2 = inplanes * 2
+        self.conv1 = nn.Sequential(convbn_3d(inplanes, c2, kernel_size=3, stride=2, pad=1), HipReLU(inplace=True))
+        self.conv2 = convbn_3d(c2, c2, kernel_size=3, stride=1, pad=1)
+        self.conv3 = nn.Sequential(convbn_3d(c2, c2, kernel_size=3, stride=2, pad=1), HipReLU(inplace=True))
+        self.conv4 = nn.Sequential(convbn_3d(c2, c2, kernel_size=3, stride=1, pad=1), HipReLU(inplace=True))
+        self.conv5 = nn.Sequential(
+            HipConvTranspose3d(c2, c2, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+            HipGroupNorm(NUM_GROUPS, c2))
+        self.conv6 = nn.Sequential(
+            HipConvTranspose3d(c2, inplanes, kernel_size=3, padding=1, output_padding=(1, 1, 1), stride=2, bias=False),
+            HipGroupNorm(NUM_GROUPS, inplanes))
+
+    def forward(self, x, presqu, postsqu, residual=None):
+        """`residual` (extension): added to `out` inside the last GroupNorm kernel (cmfsm.py:687,690,693)."""
+        out = _cbn(self.conv1[0], x, relu=True)                                   # :285
+        pre = _cbn(self.conv2, out, skip=postsqu, relu=True)                      # :286-290
+        out = _cbn(self.conv3[0], pre, relu=True)                                 # :292
+        out = _cbn(self.conv4[0], out, relu=True)                                 # :293
+        post = _cbn(self.conv5, out, skip=presqu if presqu is not None else pre, relu=True)   # :295-299
+        out = _cbn(self.conv6, post, skip=residual, relu=False)                   # :301
+        return out, pre, post
+
+
+class similarity_measure1(nn.Module):
+    """Per-pixel MLP as 1x1 convs 66->32->16->8->1, LeakyReLU between, no bias (cmfsm.py:304-358).
+    Parameter holder for the fused ECM-weights kernel; calling it directly runs the plain 1x1 convs."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 32
+        self.conv0 = nn.Conv2d(66, 32, kernel_size=1, bias=False)
+        self.relu0 = nn.LeakyReLU(inplace=True)
+        self.conv1 = nn.Conv2d(32, 16, kernel_size=1, bias=False)
+        self.relu1 = nn.LeakyReLU(inplace=True)
+        self.conv2 = nn.Conv2d(16, 8, kernel_size=1, bias=False)
+        self.relu2 = nn.LeakyReLU(inplace=True)
+        self.conv3 = nn.Conv2d(8, 1, kernel_size=1, bias=False)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = self.relu0(self.conv0(x))
+        x = self.relu1(self.conv1(x))
+        x = self.relu2(self.conv2(x))
+        return self.conv3(x)
+
+
+class eight_related_context_mapping(nn.Module):
+    """cmfsm.py:431-593 -> nine softmax planes [B,1,H,W] (centre,l,r,t,b,lt,rt,lb,rb)."""
+
+    def __init__(self):
+        super().__init__()
+        self.similarity1 = similarity_measure1()
+        self.sigmoid = nn.Sigmoid()
+
+    def weights(self, lr_feature, hr_feature):
+        m = self.similarity1
+        return ops.ecm_weights9(lr_feature, hr_feature, m.conv0.weight, m.conv1.weight, m.conv2.weight, m.conv3.weight)
+
+    def forward(self, lr_feature, hr_feature, lr_feature_r=None, hr_feature_r=None):
+        w9 = self.weights(lr_feature, hr_feature)          # right-image inputs are ignored (cmfsm.py:474-480)
+        return tuple(w9[:, n:n + 1] for n in range(9))
+
+
+class cmfsm(nn.Module):
+    """cmfsm.py:594-774.  forward(left, right) -> (pred1, pred2, pred3), each [B,1,H,W] in pixels."""
+
+    def __init__(self, maxdisp=192):
+        super().__init__()
+        self.maxdisp = maxdisp
+        self.feature_extraction = feature_extraction()
+        self.dres0 = nn.Sequential(convbn_3d(64, 32, 3, 1, 1), HipReLU(inplace=True),
+                                   convbn_3d(32, 32, 3, 1, 1), HipReLU(inplace=True))
+        self.dres1 = nn.Sequential(convbn_3d(32, 32, 3, 1, 1), HipReLU(inplace=True),
+                                   convbn_3d(32, 32, 3, 1, 1))
+        self.dres2 = hourglass(32)
+        self.dres3 = hourglass(32)
+        self.dres4 = hourglass(32)
+        for i in (1, 2, 3):
+            setattr(self, f"classif{i}", nn.Sequential(
+                convbn_3d(32, 32, 3, 1, 1), HipReLU(inplace=True),
+                HipConv3d(32, 1, kernel_size=3, padding=1, stride=1, bias=False)))
+        self.mapping_matrix = eight_related_context_mapping()
+        # the reference re-initialises every Conv2d/Conv3d with the PSMNet rule (cmfsm.py:638-645)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(0, math.sqrt(2.0 / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
+            elif isinstance(m, nn.Conv3d):
+                k = m.kernel_size
+                m.weight.data.normal_(0, math.sqrt(2.0 / (k[0] * k[1] * k[2] * m.out_channels)))
+
+    def hot_path(self, lr_l, hr_l, lr_r):
+        """Everything after the encoder (cmfsm.py:659-774)."""
+        scale = hr_l.shape[-1] // lr_l.shape[-1]
+        w9 = self.mapping_matrix.weights(lr_l, hr_l)                                   # :664
+        cost = ops.cost_volume(lr_l, lr_r, self.maxdisp // scale)                      # :667-682
+        cost0 = _cbn(self.dres0[0], cost, relu=True)                                   # :684
+        cost0 = _cbn(self.dres0[2], cost0, relu=True)
+        y = _cbn(self.dres1[0], cost0, relu=True)                                      # :685
+        cost0 = _cbn(self.dres1[2], y, skip=cost0)
+        out1, pre1, post1 = self.dres2(cost0, None, None, residual=cost0)              # :686-687
+        out2, pre2, post2 = self.dres3(out1, pre1, post1, residual=cost0)              # :689-690
+        out3, pre3, post3 = self.dres4(out2, pre1, post2, residual=cost0)              # :692-693
+        heads = []
+        for clf, out in ((self.classif1, out1), (self.classif2, out2), (self.classif3, out3)):
+            heads.append(clf[2](_cbn(clf[0], out, relu=True)).squeeze(1))               # :695,724,747
+        disp = ops.softargmin_heads(torch.stack(heads, 0))                             # :703-706,725-728,748-753
+        preds = ops.ecm_aggregate9(disp, w9, scale)                                    # :709-723 (x3)
+        return preds[0].unsqueeze(1), preds[1].unsqueeze(1), preds[2].unsqueeze(1)
+
+    def forward(self, left, right):
+        lr_l, _, hr_l = self.feature_extraction(left)                                  # :657
+        lr_r, _, _ = self.feature_extraction(right)                                    # :658
+        return self.hot_path(lr_l, hr_l, lr_r)
+
+
+_MODELS = {"cmfsm": cmfsm}
+
+
+def get_model(name):
+    """cmf/models/__init__.py:19-41: returns `cls()`; an unknown name prints and returns None like the reference."""
+    cls = _MODELS.get(name)
+    if cls is None:
+        print("Model {} not available".format(name))
+        return None
+    return cls()

@@ -1,0 +1,357 @@
+"""torch.autograd.Function skins over the C ABI of libecm_hip.so.
+
+PyTorch is plumbing here (device memory from its caching allocator, the current HIP stream,
+autograd bookkeeping); every forward and backward below is a hand-written gfx950 kernel reached
+through `_lib.call`.  There is no eager/CPU fallback: a non-CUDA tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+GN_GROUPS = 32
+GN_EPS = 1e-5
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("ecm ops run only on the MI355X HIP path: got a CPU tensor (no CPU fallback exists)")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"ecm ops are fp32 (got {t.dtype})")
+
+
+def _c(t):
+    """Contiguous and 16-byte aligned (the kernels use float4 accesses)."""
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _scratch(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------ a1 cost volume
+class CostVolumeConcat(torch.autograd.Function):
+    """cmfsm.py:667-682 -- [B,C,h,w] x2 -> [B,2C,D,h,w]."""
+
+    @staticmethod
+    def forward(ctx, left, right, ndisp):
+        _chk(left, right)
+        left, right = _c(left), _c(right)
+        B, Cc, h, w = left.shape
+        cost = torch.empty(B, 2 * Cc, ndisp, h, w, device=left.device, dtype=left.dtype)
+        _lib.call("ecm_costvol_concat_fwd", _p(left), _p(right), _p(cost), B, Cc, h, w, ndisp, _stream())
+        ctx.dims = (B, Cc, h, w, ndisp)
+        return cost
+
+    @staticmethod
+    def backward(ctx, gcost):
+        B, Cc, h, w, D = ctx.dims
+        gcost = _c(gcost)
+        gl = torch.empty(B, Cc, h, w, device=gcost.device, dtype=gcost.dtype)
+        gr = torch.empty_like(gl)
+        _lib.call("ecm_costvol_concat_bwd", _p(gcost), _p(gl), _p(gr), B, Cc, h, w, D, _stream())
+        return gl, gr, None
+
+
+def cost_volume(left, right, ndisp):
+    return CostVolumeConcat.apply(left, right, int(ndisp))
+
+
+# ------------------------------------------------------------------------------------ a8 soft-argmin
+class SoftArgminHeads(torch.autograd.Function):
+    """c [NH,B,D,h,w] raw classifier outputs -> disp [NH,B,h,w]; head k uses logits c_0+...+c_k
+    (cmfsm.py:703-706, 725-728, 748-753)."""
+
+    @staticmethod
+    def forward(ctx, c):
+        _chk(c)
+        c = _c(c)
+        NH, B, D, h, w = c.shape
+        disp = torch.empty(NH, B, h, w, device=c.device, dtype=c.dtype)
+        _lib.call("ecm_softargmin_heads_fwd", _p(c), C.c_longlong(B * D * h * w), _p(disp), NH, B, D, h * w, _stream())
+        ctx.save_for_backward(c)
+        return disp
+
+    @staticmethod
+    def backward(ctx, gdisp):
+        (c,) = ctx.saved_tensors
+        NH, B, D, h, w = c.shape
+        gdisp = _c(gdisp)
+        gc = torch.empty_like(c)
+        _lib.call("ecm_softargmin_heads_bwd", _p(c), C.c_longlong(B * D * h * w), _p(gdisp), _p(gc), NH, B, D, h * w,
+                  _stream())
+        return gc
+
+
+def softargmin_heads(c):
+    return SoftArgminHeads.apply(c)
+
+
+def disparity_regression(x):
+    """disparityregression.forward (cmfsm.py:120-123): [B,D,h,w] probabilities -> [B,h,w]. Forward only."""
+    _chk(x)
+    x = _c(x)
+    B, D, h, w = x.shape
+    out = torch.empty(B, h, w, device=x.device, dtype=x.dtype)
+    _lib.call("ecm_disparity_regression_fwd", _p(x), _p(out), B, D, h * w, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------ a9 aggregation
+class ECMAggregate9(torch.autograd.Function):
+    """d [NH,B,h,w], w9 [B,9,H,W] -> [NH,B,H,W]   (cmfsm.py:709-723)."""
+
+    @staticmethod
+    def forward(ctx, d, w9, scale):
+        _chk(d, w9)
+        d, w9 = _c(d), _c(w9)
+        NH, B, h, w = d.shape
+        assert w9.shape == (B, 9, h * scale, w * scale), (w9.shape, d.shape, scale)
+        out = torch.empty(NH, B, h * scale, w * scale, device=d.device, dtype=d.dtype)
+        _lib.call("ecm_aggregate9_fwd", _p(d), _p(w9), _p(out), NH, B, h, w, scale, _stream())
+        ctx.save_for_backward(d, w9)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        d, w9 = ctx.saved_tensors
+        NH, B, h, w = d.shape
+        gout = _c(gout)
+        gd, gw9 = torch.empty_like(d), torch.empty_like(w9)
+        _lib.call("ecm_aggregate9_bwd", _p(d), _p(w9), _p(gout), _p(gd), _p(gw9), NH, B, h, w, ctx.scale, _stream())
+        return gd, gw9, None
+
+
+def ecm_aggregate9(d, w9, scale):
+    return ECMAggregate9.apply(d, w9, int(scale))
+
+
+# ------------------------------------------------------------------------------------ a3 ECM weights
+class ECMWeights9(torch.autograd.Function):
+    """eight_related_context_mapping (cmfsm.py:443-593): lr [B,32,h,w], hr [B,32,H,W] -> w9 [B,9,H,W]."""
+
+    @staticmethod
+    def forward(ctx, lr, hr, W0, W1, W2, W3):
+        _chk(lr, hr, W0, W1, W2, W3)
+        lr, hr = _c(lr), _c(hr)
+        W0, W1, W2, W3 = (_c(t) for t in (W0, W1, W2, W3))
+        B, Cc, h, w = lr.shape
+        H, W = hr.shape[-2:]
+        s = W // w
+        if s % 2 != 0:
+            raise ValueError("odd scale between hr and lr features (the reference calls exit() here, cmfsm.py:448-449)")
+        if Cc != 32 or hr.shape[1] != 32 or H != h * s or W != w * s:
+            raise RuntimeError(f"ecm_weights9: unsupported shapes lr {tuple(lr.shape)} hr {tuple(hr.shape)}")
+        w9 = torch.empty(B, 9, H, W, device=lr.device, dtype=lr.dtype)
+        nb = _lib.query("ecm_weights9_scratch_bytes", B, h, w)
+        scratch = _scratch(nb, lr.device)
+        _lib.call("ecm_weights9_fwd", _p(lr), _p(hr), _p(W0), _p(W1), _p(W2), _p(W3), _p(w9), _p(scratch),
+                  C.c_longlong(nb), B, h, w, s, _stream())
+        ctx.save_for_backward(lr, hr, W0, W1, W2, W3, w9)
+        ctx.s = s
+        return w9
+
+    @staticmethod
+    def backward(ctx, gw9):
+        lr, hr, W0, W1, W2, W3, w9 = ctx.saved_tensors
+        B, _, h, w = lr.shape
+        s = ctx.s
+        gw9 = _c(gw9)
+        glr, ghr = torch.empty_like(lr), torch.empty_like(hr)
+        gW = torch.empty(2112 + 512 + 128 + 8, device=lr.device, dtype=lr.dtype)
+        nb = _lib.query("ecm_weights9_bwd_scratch_bytes", B, h, w, s)
+        scratch = _scratch(nb, lr.device)
+        _lib.call("ecm_weights9_bwd", _p(lr), _p(hr), _p(W0), _p(W1), _p(W2), _p(W3), _p(w9), _p(gw9), _p(glr), _p(ghr),
+                  _p(gW), _p(scratch), C.c_longlong(nb), B, h, w, s, _stream())
+        return (glr, ghr, gW[:2112].view_as(W0), gW[2112:2624].view_as(W1), gW[2624:2752].view_as(W2),
+                gW[2752:].view_as(W3))
+
+
+def ecm_weights9(lr, hr, W0, W1, W2, W3):
+    return ECMWeights9.apply(lr, hr, W0, W1, W2, W3)
+
+
+# ------------------------------------------------------------------------------------ a5-a7 conv / deconv / GN
+def _pack_conv(w, flip_transpose=False):
+    Co, Ci = w.shape[0], w.shape[1]
+    kin, kout = (Co, Ci) if flip_transpose else (Ci, Co)
+    n = _lib.query("ecm_conv3d_packed_floats", kin, kout)
+    packed = torch.empty(n, device=w.device, dtype=w.dtype)
+    _lib.call("ecm_conv3d_pack_weight", _p(w), _p(packed), Co, Ci, int(flip_transpose), _stream())
+    return packed
+
+
+def _pack_deconv(w):
+    """w [A,Bc,3,3,3]: ConvTranspose3d weight [Ci,Co,...] (or a Conv3d weight whose stride-2 dgrad is wanted)."""
+    A, Bc = w.shape[0], w.shape[1]
+    n = _lib.query("ecm_conv3d_packed_floats", A, Bc)
+    packed = torch.empty(n, device=w.device, dtype=w.dtype)
+    _lib.call("ecm_deconv3d_pack_weight", _p(w), _p(packed), A, Bc, _stream())
+    return packed
+
+
+def _conv_fwd(x, packed, Co, stride):
+    B, Ci, D, H, W = x.shape
+    Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty(B, Co, Do, Ho, Wo, device=x.device, dtype=x.dtype)
+    _lib.call("ecm_conv3d_k3_fwd", _p(x), _p(packed), _p(y), B, Ci, Co, D, H, W, stride, _stream())
+    return y
+
+
+def _deconv_fwd(x, packed, Co, out_dhw):
+    B, Ci, D, H, W = x.shape
+    Do, Ho, Wo = out_dhw
+    y = torch.empty(B, Co, Do, Ho, Wo, device=x.device, dtype=x.dtype)
+    _lib.call("ecm_deconv3d_k3s2_fwd", _p(x), _p(packed), _p(y), B, Ci, Co, D, H, W, Do, Ho, Wo, _stream())
+    return y
+
+
+def _wgrad(x, gy, Co, Ci, stride):
+    """gw[Co,Ci,3,3,3] = sum gy[b,co,o] x[b,ci,o*stride+k-1]."""
+    B, _, D, H, W = x.shape
+    gw = torch.empty(Co, Ci, 3, 3, 3, device=x.device, dtype=x.dtype)
+    nb = _lib.query("ecm_conv3d_wgrad_scratch_bytes", B, Ci, Co, D, H, W, stride)
+    scratch = _scratch(nb, x.device)
+    _lib.call("ecm_conv3d_k3_wgrad", _p(x), _p(gy), _p(gw), _p(scratch), C.c_longlong(nb), B, Ci, Co, D, H, W, stride,
+              _stream())
+    return gw
+
+
+class Conv3dK3(torch.autograd.Function):
+    """nn.Conv3d(k=3, pad=1, stride 1|2, bias=False) (cmfsm.py:52-57)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        _chk(x, w)
+        x, w = _c(x), _c(w)
+        y = _conv_fwd(x, _pack_conv(w), w.shape[0], stride)
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _c(gy)
+        Co, Ci = w.shape[0], w.shape[1]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if ctx.stride == 1:
+                gx = _conv_fwd(gy, _pack_conv(w, True), Ci, 1) if Co % 4 == 0 else _dgrad_small_co(gy, w)
+            else:
+                gx = _deconv_fwd(gy, _pack_deconv(w), Ci, x.shape[2:])
+        if ctx.needs_input_grad[1]:
+            gw = _wgrad(x, gy, Co, Ci, ctx.stride)
+        return gx, gw, None
+
+
+def _dgrad_small_co(gy, w):
+    """Data gradient of the Cout=1 classifier conv (cmfsm.py:624): pad gy's channel dim to 4 (zeros) so the
+    MFMA kernel's k-steps stay whole."""
+    B, Co, D, H, W = gy.shape
+    Ci = w.shape[1]
+    gyp = torch.zeros(B, 4, D, H, W, device=gy.device, dtype=gy.dtype)
+    gyp[:, :Co] = gy
+    wp = torch.zeros(4, Ci, 3, 3, 3, device=w.device, dtype=w.dtype)
+    wp[:Co] = w
+    return _conv_fwd(gyp, _pack_conv(wp, True), Ci, 1)
+
+
+def conv3d_k3(x, w, stride=1):
+    return Conv3dK3.apply(x, w, int(stride))
+
+
+class Deconv3dK3S2(torch.autograd.Function):
+    """nn.ConvTranspose3d(k=3, stride=2, pad=1, output_padding=1, bias=False) (cmfsm.py:262-268)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _chk(x, w)
+        x, w = _c(x), _c(w)
+        B, Ci, D, H, W = x.shape
+        y = _deconv_fwd(x, _pack_deconv(w), w.shape[1], (2 * D, 2 * H, 2 * W))
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _c(gy)
+        Ci, Co = w.shape[0], w.shape[1]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            # gx[ci,i] = sum_{co,k} gy[co,2i+k-1] w[ci,co,k]: a stride-2 conv with w read as Conv3d [Cout=Ci,Cin=Co]
+            gx = _conv_fwd(gy, _pack_conv(w), Ci, 2)
+        if ctx.needs_input_grad[1]:
+            # gw[ci,co,k] = sum x[ci,i] gy[co,2i+k-1]: the conv-wgrad with x:=gy (big), gy:=x, "Co":=Ci, "Ci":=Co
+            gw = _wgrad(gy, x, Ci, Co, 2)
+        return gx, gw
+
+
+def deconv3d_k3s2(x, w):
+    return Deconv3dK3S2.apply(x, w)
+
+
+class GroupNormAct(torch.autograd.Function):
+    """y = relu?( GroupNorm32(x)*gamma+beta (+ skip) )  (cmfsm.py:58 + ReLU/residual at 287-299, 606-613, 685-693)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, skip, relu):
+        _chk(x, gamma, beta, skip)
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        skip = _c(skip) if skip is not None else None
+        B, Cc = x.shape[:2]
+        S = x.numel() // (B * Cc)
+        stats = torch.empty(B, GN_GROUPS, 2, device=x.device, dtype=x.dtype)
+        nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
+        scratch = _scratch(nb, x.device)
+        _lib.call("ecm_gn3d_stats", _p(x), _p(stats), _p(scratch), C.c_longlong(nb), B, Cc, C.c_longlong(S),
+                  C.c_float(GN_EPS), _stream())
+        y = torch.empty_like(x)
+        _lib.call("ecm_gn3d_apply", _p(x), _p(stats), _p(gamma), _p(beta), _p(skip), _p(y), B, Cc, C.c_longlong(S),
+                  int(relu), _stream())
+        ctx.save_for_backward(x, stats, gamma, y if relu else None)
+        ctx.relu, ctx.has_skip = relu, skip is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, gamma, y = ctx.saved_tensors
+        gy = _c(gy)
+        B, Cc = x.shape[:2]
+        S = x.numel() // (B * Cc)
+        gx = torch.empty_like(x)
+        gskip = torch.empty_like(x) if ctx.has_skip else None
+        if ctx.has_skip and not ctx.relu:
+            gskip = gy                      # no mask: the skip gradient is gy itself
+        ggamma = torch.zeros_like(gamma)
+        gbeta = torch.zeros_like(gamma)
+        nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
+        scratch = _scratch(nb, x.device)
+        _lib.call("ecm_gn3d_bwd", _p(x), _p(stats), _p(gamma), _p(y), _p(gy), _p(gx),
+                  _p(gskip if (ctx.has_skip and ctx.relu) else None), _p(ggamma), _p(gbeta), _p(scratch),
+                  C.c_longlong(nb), B, Cc, C.c_longlong(S), int(ctx.relu), _stream())
+        return gx, ggamma, gbeta, gskip, None
+
+
+def group_norm_act(x, gamma, beta, skip=None, relu=False):
+    return GroupNormAct.apply(x, gamma, beta, skip, bool(relu))

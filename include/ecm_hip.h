@@ -1,0 +1,123 @@
+/*
+ * ecm_hip.h -- C ABI of libecm_hip.so: the MI355X (gfx950) hot path of the
+ * Explicit-Context-Mapping stereo network (reference: cmf/models/cmfsm.py).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and ints only; every pointer is a DEVICE pointer that the
+ *     caller owns (borrowed; kernels never allocate, free or synchronise);
+ *   - tensors are contiguous fp32, NCHW / NCDHW exactly as the reference holds them;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); work is
+ *     enqueued asynchronously on it;
+ *   - return 0 on success, a negative ECM_E* code on a bad argument, or the positive
+ *     hipError_t of a failed launch; no exceptions cross the ABI;
+ *   - re-entrant, no global mutable state.
+ *
+ * Each function cites the reference interface (file:line under the reference repo)
+ * it replaces; INTEGRATION.md shows the ctypes binding a maintainer would add.
+ */
+#ifndef ECM_HIP_H
+#define ECM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECM_EINVAL   (-1)   /* bad shape / null pointer */
+#define ECM_EUNSUP   (-2)   /* shape outside what the kernels are built for */
+#define ECM_ESCRATCH (-3)   /* caller-provided scratch too small */
+
+/* Library / build info. */
+int         ecm_abi_version(void);            /* bumps on any signature change */
+const char* ecm_error_string(int code);       /* for both ECM_E* and hipError_t codes */
+
+/* ---- a1: cost volume (cmfsm.py:667-682; == cat_d matchshifted, cmfsm.py:88-108) ------------
+ * cost[b, c,   d, y, x] = L[b,c,y,x]     if x >= d else 0
+ * cost[b, C+c, d, y, x] = R[b,c,y,x-d]   if x >= d else 0
+ * L,R: [B,C,h,w]; cost: [B,2C,D,h,w].  fwd writes every element (no pre-zeroing needed). */
+int ecm_costvol_concat_fwd(const float* L, const float* R, float* cost,
+                           int B, int C, int h, int w, int D, void* stream);
+/* gL[b,c,y,x] = sum_{d<=x} gcost[b,c,d,y,x];  gR[b,c,y,x'] = sum_{d, x'+d<w} gcost[b,C+c,d,y,x'+d] */
+int ecm_costvol_concat_bwd(const float* gcost, float* gL, float* gR,
+                           int B, int C, int h, int w, int D, void* stream);
+
+/* ---- a8: soft-argmin over D (cmfsm.py:703-706 + disparityregression 111-123) -----------------
+ * Fused three-head form: logits_k = sum_{j<=k} c_j (cmfsm.py:725,748), disp[k] = sum_d softmax_d(logits_k)*d.
+ * c: nheads pointers' worth of [B,D,h*w] raw classifier outputs packed as c[head] = c0 + head*head_stride.
+ * disp: [nheads,B,h*w].  nheads in 1..3. */
+int ecm_softargmin_heads_fwd(const float* c0, long long head_stride, float* disp,
+                             int nheads, int B, int D, int hw, void* stream);
+/* gc[head] (same packing as c) from gdisp [nheads,B,hw]; recomputes the softmax. */
+int ecm_softargmin_heads_bwd(const float* c0, long long head_stride, const float* gdisp, float* gc0,
+                             int nheads, int B, int D, int hw, void* stream);
+/* disparityregression.forward alone (cmfsm.py:120-123): out[b,p] = sum_d x[b,d,p]*d */
+int ecm_disparity_regression_fwd(const float* x, float* out, int B, int D, int hw, void* stream);
+
+/* ---- a9: NN-upsample x scale + 9-neighbour weighted sum (cmfsm.py:709-723, 730-744, 755-769) --
+ * out[k,b,Y,X] = sum_n w9[b,n,Y,X] * s * d[k,b,Y/s+dy_n,X/s+dx_n]   (0 outside), n order: c,l,r,t,b,lt,rt,lb,rb
+ * d: [nheads,B,h,w]; w9: [B,9,H,W] (H=h*s, W=w*s); out: [nheads,B,H,W]. */
+int ecm_aggregate9_fwd(const float* d, const float* w9, float* out,
+                       int nheads, int B, int h, int w, int s, void* stream);
+int ecm_aggregate9_bwd(const float* d, const float* w9, const float* gout, float* gd, float* gw9,
+                       int nheads, int B, int h, int w, int s, void* stream);
+
+/* ---- a3: eight-related context-mapping weights (cmfsm.py:431-593, 304-358, 391-428) ----------
+ * lr: [B,32,h,w]; hr: [B,32,H,W]; W0 [32,66], W1 [16,32], W2 [8,16], W3 [1,8] (1x1 conv weights, no bias);
+ * w9: [B,9,H,W] softmax planes in the reference's return order.
+ * scratch: >= ecm_weights9_scratch_bytes(B,h,w) bytes of device memory. */
+long long ecm_weights9_scratch_bytes(int B, int h, int w);
+int ecm_weights9_fwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2,
+                     const float* W3, float* w9, void* scratch, long long scratch_bytes,
+                     int B, int h, int w, int s, void* stream);
+/* Gradients of all inputs from gw9 [B,9,H,W].  gW = [gW0(2112) | gW1(512) | gW2(128) | gW3(8)] floats. */
+long long ecm_weights9_bwd_scratch_bytes(int B, int h, int w, int s);
+int ecm_weights9_bwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2,
+                     const float* W3, const float* w9, const float* gw9,
+                     float* glr, float* ghr, float* gW, void* scratch, long long scratch_bytes,
+                     int B, int h, int w, int s, void* stream);
+
+/* ---- a5-a7: 3-D aggregation (cmfsm.py:49-58 convbn_3d, 240-303 hourglass, 604-634) ----------
+ * Weights are taken in the reference (checkpoint) layouts and repacked on device by the *_pack calls. */
+
+/* Repack Conv3d weight [Co,Ci,3,3,3] -> kernel layout [27][Ci][CoP] (CoP = Co rounded up to 32).
+ * flip_transpose != 0 packs the data-gradient operator of a stride-1 conv instead (taps reversed, Ci/Co
+ * swapped: a conv with Cin'=Co, Cout'=Ci), so dgrad runs on ecm_conv3d_k3_fwd too. */
+long long ecm_conv3d_packed_floats(int Ci, int Co);
+int ecm_conv3d_pack_weight(const float* w, float* packed, int Co, int Ci, int flip_transpose, void* stream);
+
+/* y[b,co,od,oh,ow] = sum w[co,ci,kd,kh,kw] x[b,ci,od*st+kd-1,oh*st+kh-1,ow*st+kw-1]; k=3, pad=1, st in {1,2}.
+ * x: [B,Ci,D,H,W]; y: [B,Co,Do,Ho,Wo] with Do=(D-1)/st+1 etc.  Ci % 4 == 0; 1 <= Co <= 64. */
+int ecm_conv3d_k3_fwd(const float* x, const float* wpacked, float* y,
+                      int B, int Ci, int Co, int D, int H, int W, int stride, void* stream);
+
+/* ConvTranspose3d k=3, stride 2, pad 1, output_padding 1 (cmfsm.py:262-281): x [B,Ci,D,H,W] -> y [B,Co,Do,Ho,Wo],
+ * Do = 2D (or 2D-1 when used as the data gradient of a stride-2 conv over an odd extent).
+ * Weight in the reference layout [Ci,Co,3,3,3]; a Conv3d weight [Co_f,Ci_f,27] is the same memory layout
+ * for its own data gradient (Ci := Co_f, Co := Ci_f).  packed: 27*Ci*CoP floats. */
+int ecm_deconv3d_pack_weight(const float* w, float* packed, int Ci, int Co, void* stream);
+int ecm_deconv3d_k3s2_fwd(const float* x, const float* wpacked, float* y,
+                          int B, int Ci, int Co, int D, int H, int W, int Do, int Ho, int Wo, void* stream);
+
+/* gw[co,ci,27] (reference Conv3d layout) = sum_{b,o} gy[b,co,o] * x[b,ci,o*st+k-1].
+ * x: [B,Ci,D,H,W], gy: [B,Co,Do,Ho,Wo]; scratch >= ecm_conv3d_wgrad_scratch_bytes(...) */
+long long ecm_conv3d_wgrad_scratch_bytes(int B, int Ci, int Co, int D, int H, int W, int stride);
+int ecm_conv3d_k3_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
+                        int B, int Ci, int Co, int D, int H, int W, int stride, void* stream);
+
+/* GroupNorm(32 groups, eps) over [B,C,S] (S = D*H*W), cmfsm.py:58; deterministic two-stage reductions.
+ * scratch for all three calls: >= ecm_gn3d_scratch_bytes(B,C,S).
+ * stats: mean_rstd [B,32,2].  apply: y = relu?( (x-mean)*rstd*gamma[c]+beta[c] (+ skip) )  (skip may be NULL). */
+long long ecm_gn3d_scratch_bytes(int B, int C, long long S);
+int ecm_gn3d_stats(const float* x, float* mean_rstd, void* scratch, long long scratch_bytes,
+                   int B, int C, long long S, float eps, void* stream);
+int ecm_gn3d_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                   const float* skip, float* y, int B, int C, long long S, int relu, void* stream);
+/* Backward of y = relu?(gn(x) + skip): writes gx and gskip (NULL to skip it); ACCUMULATES into ggamma[C], gbeta[C].
+ * y is the forward OUTPUT (relu mask; may be NULL when relu == 0). */
+int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* y, const float* gy,
+                 float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch, long long scratch_bytes,
+                 int B, int C, long long S, int relu, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECM_HIP_H */

@@ -1,0 +1,452 @@
+// Backward of the eight-related ECM weights (autograd of eight_related_context_mapping.forward,
+// cmfsm.py:443-593): gradients w.r.t. lr, hr and the 2,760 MLP weights from gw9 [B,9,H,W].
+//
+// Kernel B (per HR pixel, one wave per 64 consecutive X of one row, workgroup = 4 rows = one LR cell row):
+//   softmax backward -> g_logit[n]; per in-image neighbour recompute the MLP and back-propagate to g0 = dL/d(h0pre).
+//   * ghr        = W0_hr^T sum_n g0                       (per pixel, registers)
+//   * gA9[cell,n] = sum over the cell's 16 pixels of g0   (per source cell and neighbour; plain stores, no atomics)
+//   * weight gradients are sums over PIXELS of per-pixel outer products, i.e. GEMMs whose reduction index is
+//     the lane: each wave transposes the operands through a [64 px][48] LDS scratch and reduces them on the
+//     fp32 matrix cores (v_mfma_f32_16x16x4_f32, K = 4 pixels per step); accumulators persist across tiles.
+// Kernel C (per LR cell): gA = sum_n gA9[cell - d_n, n];  glr = W0_lr^T gA;  gW0_lr partials.
+// Kernel D: fixed-order sum of the per-workgroup partials -> gW (deterministic).
+// Scale 4 only (cmfsm); other scales return ECM_EUNSUP.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CF = 32, S = 4, TX = 64, TY = 4;
+constexpr int ASTRIDE = 36;
+constexpr int NCX = TX / S + 2, NCY = 3;              // cell window of a tile (+1 halo)
+constexpr int UST = 48;                               // per-pixel stride of the transpose scratch (== 16 mod 32)
+constexpr int PB_HR = 0, PB_OFF = 1024, PB_W1 = 1088, PB_W2 = 1600, PB_W3 = 1728, PB_N = 1736;   // partial layout
+
+__constant__ int bDy9[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+__constant__ int bDx9[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
+__constant__ int bTab9[9] = {0, 1, 2, 3, 4, 1, 2, 3, 4};
+
+__device__ __forceinline__ float cpat(int r) { return (float)(r < S / 2 ? r - S / 2 : r - S / 2 + 1); }
+__device__ __forceinline__ float offx(int t, int r) { return t == 1 ? (float)(S - r) : t == 2 ? (float)(r + 1) : cpat(r); }
+__device__ __forceinline__ float offy(int t, int r) { return t == 3 ? (float)(S - r) : t == 4 ? (float)(r + 1) : cpat(r); }
+__device__ __forceinline__ float dleaky(float h) { return h > 0.f ? 1.f : 0.01f; }      // phi'(pre); sign(h)==sign(pre)
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS ops of one wave execute in issue order; this only stops the compiler from reordering across it.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A[b, cell, j] = sum_c W0[j, c] lr[b, c, cell]  (same as the forward's projection)
+__global__ __launch_bounds__(256) void bwd_lr_proj(const float* __restrict__ lr, const float* __restrict__ W0,
+                                                   float* __restrict__ A, int B, int hw) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * hw) return;
+    const int b = (int)(i / hw), p = (int)(i - (long long)b * hw);
+    float v[CF];
+#pragma unroll
+    for (int c = 0; c < CF; ++c) v[c] = lr[((size_t)b * CF + c) * hw + p];
+    float4* out = reinterpret_cast<float4*>(A + (size_t)i * CF);
+#pragma unroll
+    for (int j = 0; j < CF; j += 4) {
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CF; ++c) acc = fmaf(W0[(j + u) * 66 + c], v[c], acc);
+            o[u] = acc;
+        }
+        out[j / 4] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void ecm_weights9_bwd_kernel(
+    const float* __restrict__ A, const float* __restrict__ hr, const float* __restrict__ W0, const float* __restrict__ W1,
+    const float* __restrict__ W2, const float* __restrict__ W3, const float* __restrict__ w9, const float* __restrict__ gw9,
+    float* __restrict__ ghr, float* __restrict__ gA9, float* __restrict__ partB, int B, int h, int w, int tiles_x) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                   // [NCY*NCX][ASTRIDE]
+    float* Uall = As + NCY * NCX * ASTRIDE;             // [4 waves][64][UST]
+    float* Rs = Uall + 4 * 64 * UST;                    // [4 waves][16 cells][32]
+    const int H = h * S, W = w * S;
+    const size_t HW = (size_t)H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    float* U = Uall + wave * 64 * UST;
+
+    // persistent accumulators (per wave): MFMA tiles + 8 per-lane sums for W3
+    f32x4 accW1[2], accW2, accOff[2], accHr[2][2];
+    float accW3[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accW1[0][i] = accW1[1][i] = accW2[i] = accOff[0][i] = accOff[1][i] = 0.f;
+        accHr[0][0][i] = accHr[0][1][i] = accHr[1][0][i] = accHr[1][1][i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accW3[i] = 0.f;
+
+    const long long ntiles = (long long)B * h * tiles_x;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x);
+        const int cy = (int)((tile / tiles_x) % h);
+        const int b = (int)(tile / ((long long)tiles_x * h));
+        const int X0 = tx * TX, Y0 = cy * S;
+        const int cx0 = X0 / S - 1, cy0 = cy - 1;
+        __syncthreads();
+        for (int e = tid; e < NCY * NCX * (CF / 4); e += 256) {
+            const int q = e % (CF / 4), cell = e / (CF / 4);
+            const int yy = cy0 + cell / NCX, xx = cx0 + cell % NCX;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w)
+                v = reinterpret_cast<const float4*>(A + (((size_t)b * h + yy) * w + xx) * CF)[q];
+            *reinterpret_cast<float4*>(As + cell * ASTRIDE + q * 4) = v;
+        }
+        __syncthreads();
+        const int Y = Y0 + wave, X = X0 + lane;
+        const bool valid = X < W;                         // right-edge partial tiles: dead lanes carry zeros
+        const int Xc = valid ? X : W - 1;
+        const size_t pix = (size_t)Y * W + Xc;
+        const float* hp = hr + (size_t)b * CF * HW + pix;
+        const int cx = Xc / S, ry = wave, rx = Xc - cx * S;
+
+        float Bv[CF];
+        {
+            float hv[CF];
+#pragma unroll
+            for (int c = 0; c < CF; ++c) hv[c] = hp[(size_t)c * HW];
+#pragma unroll
+            for (int j = 0; j < CF; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < CF; ++c) acc = fmaf(W0[j * 66 + 32 + c], hv[c], acc);
+                Bv[j] = acc;
+            }
+        }
+        // softmax backward: gl[n] = w[n] (gw[n] - sum_m w[m] gw[m])
+        float gl[9];
+        {
+            float wv[9], dot = 0.f;
+#pragma unroll
+            for (int n = 0; n < 9; ++n) {
+                wv[n] = w9[((size_t)b * 9 + n) * HW + pix];
+                gl[n] = gw9[((size_t)b * 9 + n) * HW + pix];
+                dot = fmaf(wv[n], gl[n], dot);
+            }
+#pragma unroll
+            for (int n = 0; n < 9; ++n) gl[n] = valid ? wv[n] * (gl[n] - dot) : 0.f;
+        }
+        float gBv[CF];
+#pragma unroll
+        for (int j = 0; j < CF; ++j) gBv[j] = 0.f;
+
+#pragma unroll 1
+        for (int n = 0; n < 9; ++n) {
+            const int yy = cy + bDy9[n];
+            if (yy < 0 || yy >= h) continue;              // workgroup-uniform (one cell row per workgroup)
+            const int xx = cx + bDx9[n];
+            const bool inb = xx >= 0 && xx < w;
+            const float g = inb ? gl[n] : 0.f;            // out-of-image neighbours carry the constant -100: no gradient
+            const int tab = bTab9[n];
+            const float ox = offx(tab, rx), oy = offy(tab, ry);
+            const int xcl = min(max(xx, cx0), cx0 + NCX - 1);
+            const float* a = As + ((yy - cy0) * NCX + (xcl - cx0)) * ASTRIDE;
+            // ---- forward recompute --------------------------------------------------------------------
+            float h0[CF];
+#pragma unroll
+            for (int j = 0; j < CF; j += 4) {
+                const float4 av = *reinterpret_cast<const float4*>(a + j);
+                h0[j + 0] = leaky(fmaf(W0[(j + 0) * 66 + 65], oy, fmaf(W0[(j + 0) * 66 + 64], ox, av.x + Bv[j + 0])));
+                h0[j + 1] = leaky(fmaf(W0[(j + 1) * 66 + 65], oy, fmaf(W0[(j + 1) * 66 + 64], ox, av.y + Bv[j + 1])));
+                h0[j + 2] = leaky(fmaf(W0[(j + 2) * 66 + 65], oy, fmaf(W0[(j + 2) * 66 + 64], ox, av.z + Bv[j + 2])));
+                h0[j + 3] = leaky(fmaf(W0[(j + 3) * 66 + 65], oy, fmaf(W0[(j + 3) * 66 + 64], ox, av.w + Bv[j + 3])));
+            }
+            float h1[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < CF; ++j) acc = fmaf(W1[i * CF + j], h0[j], acc);
+                h1[i] = leaky(acc);
+            }
+            float h2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc = fmaf(W2[i * 16 + j], h1[j], acc);
+                h2[i] = leaky(acc);
+            }
+            // ---- backward chain -----------------------------------------------------------------------
+            float g2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                accW3[i] = fmaf(g, h2[i], accW3[i]);
+                g2[i] = W3[i] * g * dleaky(h2[i]);
+            }
+            float g1[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc = fmaf(W2[i * 16 + j], g2[i], acc);
+                g1[j] = acc * dleaky(h1[j]);
+            }
+            // (1) gW1 += g1^T h0 over the wave's 64 pixels
+#pragma unroll
+            for (int j = 0; j < CF; j += 4) *reinterpret_cast<float4*>(U + lane * UST + j) = make_float4(h0[j], h0[j + 1], h0[j + 2], h0[j + 3]);
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(U + lane * UST + 32 + j) = make_float4(g1[j], g1[j + 1], g1[j + 2], g1[j + 3]);
+            wave_lds_sync();
+#pragma unroll
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                const float* up = U + (k0 + l4) * UST;
+                const float av = up[32 + l15];
+                accW1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, up[l15], accW1[0], 0, 0, 0);
+                accW1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, up[16 + l15], accW1[1], 0, 0, 0);
+            }
+            wave_lds_sync();
+            // g0 = (W1^T g1) * phi'(h0)   (overwrites h0)
+#pragma unroll
+            for (int c = 0; c < CF; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc = fmaf(W1[i * CF + c], g1[i], acc);
+                h0[c] = acc * dleaky(h0[c]);
+                gBv[c] += h0[c];
+            }
+            // (2) gW0[:,64:66] += g0^T [ox,oy];  cell sums of g0 -> gA9
+#pragma unroll
+            for (int j = 0; j < CF; j += 4) *reinterpret_cast<float4*>(U + lane * UST + j) = make_float4(h0[j], h0[j + 1], h0[j + 2], h0[j + 3]);
+            *reinterpret_cast<float2*>(U + lane * UST + 32) = make_float2(ox, oy);
+            wave_lds_sync();
+#pragma unroll
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                const float* up = U + (k0 + l4) * UST;
+                const float bvv = l15 < 2 ? up[32 + l15] : 0.f;
+                accOff[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[l15], bvv, accOff[0], 0, 0, 0);
+                accOff[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[16 + l15], bvv, accOff[1], 0, 0, 0);
+            }
+            {   // lane -> (cell = lane>>2, 8 channels = (lane&3)*8..): sum the cell's 4 pixels of this row
+                const int cell = lane >> 2, j0 = (lane & 3) * 8;
+                float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const float4 u0 = *reinterpret_cast<const float4*>(U + (cell * 4 + pp) * UST + j0);
+                    const float4 u1 = *reinterpret_cast<const float4*>(U + (cell * 4 + pp) * UST + j0 + 4);
+                    s0.x += u0.x; s0.y += u0.y; s0.z += u0.z; s0.w += u0.w;
+                    s1.x += u1.x; s1.y += u1.y; s1.z += u1.z; s1.w += u1.w;
+                }
+                *reinterpret_cast<float4*>(Rs + (wave * 16 + cell) * CF + j0) = s0;
+                *reinterpret_cast<float4*>(Rs + (wave * 16 + cell) * CF + j0 + 4) = s1;
+            }
+            __syncthreads();
+            for (int e = tid; e < 16 * CF; e += 256) {       // sum the 4 rows of each cell in a fixed order
+                const int cell = e / CF, j = e - cell * CF;
+                const int cxs = X0 / S + cell;
+                if (cxs < w) {
+                    const float v = (Rs[(0 * 16 + cell) * CF + j] + Rs[(1 * 16 + cell) * CF + j]) +
+                                    (Rs[(2 * 16 + cell) * CF + j] + Rs[(3 * 16 + cell) * CF + j]);
+                    gA9[((((size_t)b * h + cy) * w + cxs) * 9 + n) * CF + j] = v;
+                }
+            }
+            __syncthreads();
+            // (3) gW2 += g2^T h1
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(U + lane * UST + j) = make_float4(h1[j], h1[j + 1], h1[j + 2], h1[j + 3]);
+#pragma unroll
+            for (int j = 0; j < 8; j += 4) *reinterpret_cast<float4*>(U + lane * UST + 16 + j) = make_float4(g2[j], g2[j + 1], g2[j + 2], g2[j + 3]);
+            wave_lds_sync();
+#pragma unroll
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                const float* up = U + (k0 + l4) * UST;
+                const float av = l15 < 8 ? up[16 + l15] : 0.f;
+                accW2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, up[l15], accW2, 0, 0, 0);
+            }
+            wave_lds_sync();
+        }
+        // ---- per pixel: ghr = W0_hr^T gBv ; gW0_hr += gBv^T hv ------------------------------------------
+        float hv[CF];
+#pragma unroll
+        for (int c = 0; c < CF; ++c) hv[c] = valid ? hp[(size_t)c * HW] : 0.f;
+        if (valid) {
+            float* gp = ghr + (size_t)b * CF * HW + pix;
+#pragma unroll
+            for (int c = 0; c < CF; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < CF; ++j) acc = fmaf(W0[j * 66 + 32 + c], gBv[j], acc);
+                gp[(size_t)c * HW] = acc;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CF; j += 4) *reinterpret_cast<float4*>(U + lane * UST + j) = make_float4(gBv[j], gBv[j + 1], gBv[j + 2], gBv[j + 3]);
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+#pragma unroll
+            for (int j = 0; j < 16; j += 4)
+                *reinterpret_cast<float4*>(U + lane * UST + 32 + j) = make_float4(hv[hs * 16 + j], hv[hs * 16 + j + 1], hv[hs * 16 + j + 2], hv[hs * 16 + j + 3]);
+            wave_lds_sync();
+#pragma unroll
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                const float* up = U + (k0 + l4) * UST;
+                const float bvv = up[32 + l15];
+                accHr[0][hs] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[l15], bvv, accHr[0][hs], 0, 0, 0);
+                accHr[1][hs] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[16 + l15], bvv, accHr[1][hs], 0, 0, 0);
+            }
+            wave_lds_sync();
+        }
+    }
+
+    // ---- workgroup partial: sum the 4 waves' accumulators in LDS, then one store per entry -----------------
+    __syncthreads();
+    float* P = Uall;                                     // [4 waves][PB_N] (fits: 4*1736 < 4*64*48)
+    float* pw = P + wave * PB_N;
+    // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = l4 * 4 + r;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) pw[PB_HR + (mt * 16 + row) * 32 + hs * 16 + l15] = accHr[mt][hs][r];   // gW0[j][32+c]
+            if (l15 < 2) pw[PB_OFF + (mt * 16 + row) * 2 + l15] = accOff[mt][r];                                   // gW0[j][64+o]
+        }
+        pw[PB_W1 + row * 32 + l15] = accW1[0][r];
+        pw[PB_W1 + row * 32 + 16 + l15] = accW1[1][r];
+        if (row < 8) pw[PB_W2 + row * 16 + l15] = accW2[r];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float v = wave_sum(accW3[i]);
+        if (lane == 0) pw[PB_W3 + i] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < PB_N; e += 256)
+        partB[(size_t)blockIdx.x * PB_N + e] = (P[e] + P[PB_N + e]) + (P[2 * PB_N + e] + P[3 * PB_N + e]);
+}
+
+// Kernel C: per LR cell.  gA = sum_n gA9[cell - d_n][n];  glr[c] = sum_j W0[j][c] gA[j];  per-workgroup
+// partial of gW0_lr[j][c] = sum_cells gA[j] lr[c].
+__global__ __launch_bounds__(128) void ecm_weights9_bwd_cells(const float* __restrict__ gA9, const float* __restrict__ lr,
+                                                              const float* __restrict__ W0, float* __restrict__ glr,
+                                                              float* __restrict__ partC, int B, int h, int w) {
+    __shared__ float Gs[128 * 33];
+    __shared__ float Ls[128 * 33];
+    const int hw = h * w;
+    const long long i = (long long)blockIdx.x * 128 + threadIdx.x;
+    const bool valid = i < (long long)B * hw;
+    float gA[CF], lv[CF];
+#pragma unroll
+    for (int j = 0; j < CF; ++j) { gA[j] = 0.f; lv[j] = 0.f; }
+    if (valid) {
+        const int b = (int)(i / hw), p = (int)(i - (long long)b * hw);
+        const int cy = p / w, cx = p - cy * w;
+#pragma unroll 1
+        for (int n = 0; n < 9; ++n) {
+            const int sy = cy - bDy9[n], sx = cx - bDx9[n];
+            if (sy < 0 || sy >= h || sx < 0 || sx >= w) continue;
+            const float4* src = reinterpret_cast<const float4*>(gA9 + ((((size_t)b * h + sy) * w + sx) * 9 + n) * CF);
+#pragma unroll
+            for (int q = 0; q < CF / 4; ++q) {
+                const float4 v = src[q];
+                gA[4 * q] += v.x; gA[4 * q + 1] += v.y; gA[4 * q + 2] += v.z; gA[4 * q + 3] += v.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CF; ++c) {
+            lv[c] = lr[((size_t)b * CF + c) * hw + p];
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < CF; ++j) acc = fmaf(W0[j * 66 + c], gA[j], acc);
+            glr[((size_t)b * CF + c) * hw + p] = acc;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CF; ++j) { Gs[threadIdx.x * 33 + j] = gA[j]; Ls[threadIdx.x * 33 + j] = lv[j]; }
+    __syncthreads();
+    // thread owns gW0_lr[j][c0..c0+7]
+    const int j = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 8;
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
+    for (int cell = 0; cell < 128; ++cell) {
+        const float gv = Gs[cell * 33 + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = fmaf(gv, Ls[cell * 33 + c0 + u], a[u]);
+    }
+    float* pc = partC + (size_t)blockIdx.x * 1024 + j * 32 + c0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pc[u] = a[u];
+}
+
+// Kernel D: gW = [gW0 (32x66) | gW1 (16x32) | gW2 (8x16) | gW3 (8)], fixed-order sums of the partials.
+__global__ void ecm_weights9_bwd_reduce(const float* __restrict__ partB, int nB, const float* __restrict__ partC, int nC,
+                                        float* __restrict__ gW) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2760) return;
+    float s = 0.f;
+    if (k < 2112) {
+        const int j = k / 66, c = k - j * 66;
+        if (c < 32) { for (int p = 0; p < nC; ++p) s += partC[(size_t)p * 1024 + j * 32 + c]; }
+        else if (c < 64) { for (int p = 0; p < nB; ++p) s += partB[(size_t)p * PB_N + PB_HR + j * 32 + (c - 32)]; }
+        else { for (int p = 0; p < nB; ++p) s += partB[(size_t)p * PB_N + PB_OFF + j * 2 + (c - 64)]; }
+    } else if (k < 2624) { for (int p = 0; p < nB; ++p) s += partB[(size_t)p * PB_N + PB_W1 + (k - 2112)]; }
+    else if (k < 2752) { for (int p = 0; p < nB; ++p) s += partB[(size_t)p * PB_N + PB_W2 + (k - 2624)]; }
+    else { for (int p = 0; p < nB; ++p) s += partB[(size_t)p * PB_N + PB_W3 + (k - 2752)]; }
+    gW[k] = s;
+}
+
+struct BwdPlan { long long ntiles; int tiles_x, nB, nC; long long offA, offA9, offPB, offPC, total; };
+
+inline BwdPlan plan(int B, int h, int w) {
+    BwdPlan p;
+    p.tiles_x = (w * S + TX - 1) / TX;
+    p.ntiles = (long long)B * h * p.tiles_x;
+    p.nB = (int)(p.ntiles < 1024 ? p.ntiles : 1024);
+    p.nC = (int)(((long long)B * h * w + 127) / 128);
+    const long long cells = (long long)B * h * w;
+    p.offA = 0;
+    p.offA9 = p.offA + cells * CF;
+    p.offPB = p.offA9 + cells * 9 * CF;
+    p.offPC = p.offPB + (long long)p.nB * PB_N;
+    p.total = p.offPC + (long long)p.nC * 1024;
+    return p;
+}
+
+constexpr int BWD_LDS_BYTES = (NCY * NCX * ASTRIDE + 4 * 64 * UST + 4 * 16 * CF) * 4;
+
+}  // namespace
+
+extern "C" long long ecm_weights9_bwd_scratch_bytes(int B, int h, int w, int s) {
+    if (B <= 0 || h <= 0 || w <= 0 || s != S) return 0;
+    return plan(B, h, w).total * (long long)sizeof(float);
+}
+
+extern "C" int ecm_weights9_bwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2,
+                                const float* W3, const float* w9, const float* gw9, float* glr, float* ghr, float* gW,
+                                void* scratch, long long scratch_bytes, int B, int h, int w, int s, void* stream) {
+    ECM_CHECK_ARG(lr && hr && W0 && W1 && W2 && W3 && w9 && gw9 && glr && ghr && gW && scratch && B > 0 && h > 0 && w > 0);
+    if (s != S) return ECM_EUNSUP;
+    const BwdPlan p = plan(B, h, w);
+    if (scratch_bytes < p.total * (long long)sizeof(float)) return ECM_ESCRATCH;
+    float* base = static_cast<float*>(scratch);
+    float *A = base + p.offA, *gA9 = base + p.offA9, *partB = base + p.offPB, *partC = base + p.offPC;
+    hipStream_t st = ecm_stream(stream);
+    const long long cells = (long long)B * h * w;
+    hipLaunchKernelGGL(bwd_lr_proj, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, lr, W0, A, B, h * w);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ecm_weights9_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ecm_weights9_bwd_kernel, dim3(p.nB), dim3(256), BWD_LDS_BYTES, st, A, hr, W0, W1, W2, W3, w9, gw9, ghr,
+                       gA9, partB, B, h, w, p.tiles_x);
+    hipLaunchKernelGGL(ecm_weights9_bwd_cells, dim3(p.nC), dim3(128), 0, st, gA9, lr, W0, glr, partC, B, h, w);
+    hipLaunchKernelGGL(ecm_weights9_bwd_reduce, dim3((2760 + 255) / 256), dim3(256), 0, st, partB, p.nB, partC, p.nC, gW);
+    return ECM_LAUNCH_RESULT();
+}

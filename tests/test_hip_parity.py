@@ -128,6 +128,34 @@ def test_ecm_weights_vs_oracle(ecm, cmfsm_sd, B, h, w, s):
     close(w9.sum(1), torch.ones(B, h * s, w * s), 1e-5, 1e-5)
 
 
+def test_ecm_weights_bwd_golden(ecm, cmfsm_sd):
+    g = load_golden("g2_ecm_weights")
+    lr, hr = dev(seeded("g2.lr", 1, 32, 3, 4)).requires_grad_(), dev(seeded("g2.hr", 1, 32, 12, 16)).requires_grad_()
+    Ws = [dev(t).requires_grad_() for t in _mlp(cmfsm_sd)]
+    w9 = ecm.ops.ecm_weights9(lr, hr, *Ws)
+    (w9 * dev(seeded("g2.G", 1, 9, 12, 16))).sum().backward()
+    close(lr.grad, g["g_lr"], 1e-3, 1e-5)
+    close(hr.grad, g["g_hr"], 1e-3, 1e-5)
+    for i in range(4):
+        close(Ws[i].grad, g[f"g_similarity1_conv{i}_weight"], 1e-3, 1e-5)
+
+
+@pytest.mark.parametrize("B,h,w", [(1, 8, 12), (2, 5, 33), (1, 3, 16)])
+def test_ecm_weights_bwd_vs_oracle(ecm, cmfsm_sd, B, h, w):
+    lr, hr = seeded("ewb.lr", B, 32, h, w), seeded("ewb.hr", B, 32, 4 * h, 4 * w)
+    G = seeded("ewb.G", B, 9, 4 * h, 4 * w)
+    lg, hg = dev(lr).requires_grad_(), dev(hr).requires_grad_()
+    Ws = [dev(t).requires_grad_() for t in _mlp(cmfsm_sd)]
+    (ecm.ops.ecm_weights9(lg, hg, *Ws) * dev(G)).sum().backward()
+    sd = {k: v.clone().requires_grad_() for k, v in cmfsm_sd.items() if k.startswith("mapping_matrix")}
+    lc, hc = lr.clone().requires_grad_(), hr.clone().requires_grad_()
+    (O.ecm_weights_eight(lc, hc, sd) * G).sum().backward()
+    close(lg.grad, lc.grad, 1e-3, 1e-5)
+    close(hg.grad, hc.grad, 1e-3, 1e-5)
+    for i in range(4):
+        close(Ws[i].grad, sd[f"mapping_matrix.similarity1.conv{i}.weight"].grad, 1e-3, 1e-4)
+
+
 def test_ecm_module_tuple(ecm, cmfsm_sd):
     mm = ecm.eight_related_context_mapping()
     mm.load_state_dict({k[len("mapping_matrix."):]: v for k, v in cmfsm_sd.items() if k.startswith("mapping_matrix.")})
@@ -186,6 +214,36 @@ def test_deconv3d_fwd(ecm, B, Ci, Co, dims):
     close(y, F.conv_transpose3d(x, w, None, 2, 1, 1), 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("B,Ci,Co,dims,stride", [
+    (1, 32, 32, (4, 8, 32), 1), (2, 64, 32, (4, 6, 20), 1), (1, 32, 1, (8, 8, 12), 1), (1, 32, 64, (8, 16, 24), 2),
+    (1, 64, 64, (4, 8, 12), 1), (2, 64, 64, (8, 8, 12), 2), (1, 32, 32, (5, 7, 19), 1)])
+def test_conv3d_bwd(ecm, B, Ci, Co, dims, stride):
+    x = seeded("cb3.x", B, Ci, *dims)
+    w = seeded("cb3.w", Co, Ci, 3, 3, 3) * (2.0 / (27 * Ci)) ** 0.5
+    xg, wg = dev(x).requires_grad_(), dev(w).requires_grad_()
+    y = ecm.ops.conv3d_k3(xg, wg, stride)
+    xc, wc = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = F.conv3d(xc, wc, None, stride, 1)
+    G = seeded("cb3.G", *ref.shape)
+    y.backward(dev(G)); ref.backward(G)
+    close(xg.grad, xc.grad, 1e-4, 1e-5)
+    close(wg.grad, wc.grad, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("B,Ci,Co,dims", [(1, 64, 64, (2, 4, 6)), (2, 64, 32, (3, 5, 19))])
+def test_deconv3d_bwd(ecm, B, Ci, Co, dims):
+    x = seeded("db3.x", B, Ci, *dims)
+    w = seeded("db3.w", Ci, Co, 3, 3, 3) * (2.0 / (27 * Ci)) ** 0.5
+    xg, wg = dev(x).requires_grad_(), dev(w).requires_grad_()
+    y = ecm.ops.deconv3d_k3s2(xg, wg)
+    xc, wc = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = F.conv_transpose3d(xc, wc, None, 2, 1, 1)
+    G = seeded("db3.G", *ref.shape)
+    y.backward(dev(G)); ref.backward(G)
+    close(xg.grad, xc.grad, 1e-4, 1e-5)
+    close(wg.grad, wc.grad, 1e-4, 1e-4)
+
+
 # ------------------------------------------------------------------ modules and the whole path
 def test_hourglass_golden(ecm, cmfsm_sd):
     g = load_golden("g6_hourglass")
@@ -224,6 +282,47 @@ def test_hot_path_tiny_golden(ecm, cmfsm_sd):
     for i, p in enumerate(preds, 1):
         d = (p.cpu() - g[f"pred{i}"]).abs()
         assert d.max() <= 2e-2 and d.mean() <= 1e-3, (i, d.max(), d.mean())
+
+
+def test_hot_path_tiny_grads_golden(ecm, cmfsm_sd):
+    """Backward of the whole hot path against gradients produced by the reference's autograd (fixture g7a)."""
+    g = load_golden("g7a_hotpath")
+    model = _load_hot(ecm, cmfsm_sd)
+    lr_l, hr_l, lr_r = (dev(seeded(f"g7a.{n}", 1, 32, *s)).requires_grad_() for n, s in
+                        (("lr_l", (8, 12)), ("hr_l", (32, 48)), ("lr_r", (8, 12))))
+    preds = model.hot_path(lr_l, hr_l, lr_r)
+    loss = sum((p * dev(seeded(f"g7a.G{i}", 1, 1, 32, 48))).sum() for i, p in enumerate(preds, 1))
+    loss.backward()
+    close(lr_l.grad, g["g_lr_l"], 5e-3, 5e-4)
+    close(hr_l.grad, g["g_hr_l"], 5e-3, 5e-4)
+    close(lr_r.grad, g["g_lr_r"], 5e-3, 5e-4)
+    for k, v in model.named_parameters():
+        if k.startswith("feature_extraction"):
+            continue
+        kk = k.replace(".", "_")
+        ref_norm = float(g["gn_" + kk])
+        got_norm = float(v.grad.norm()) if v.grad is not None else 0.0
+        assert abs(got_norm - ref_norm) <= 5e-3 * ref_norm + 1e-5, (k, got_norm, ref_norm)
+        if "g_" + kk in g:
+            close(v.grad, g["g_" + kk], 1e-2, 1e-3 * ref_norm / max(1.0, v.numel() ** 0.5) + 1e-5)
+
+
+def test_full_model_train_step_golden(ecm, cmfsm_sd):
+    """train.py:162-181 on the 256x512 fixture: loss and a few gradient norms vs the reference run."""
+    g = load_golden("g8_full_cmfsm_256x512")
+    model = _load_hot(ecm, cmfsm_sd).train()
+    left, right = dev(seeded("g8.left", 1, 3, 256, 512)), dev(seeded("g8.right", 1, 3, 256, 512))
+    gt = dev(torch.rand(1, 256, 512, generator=torch.Generator().manual_seed(8)) * 191.0)
+    o = model(left, right)
+    loss = O.train_loss(o, gt)
+    loss.backward()
+    close(loss, g["loss"], 1e-4, 1e-4)
+    params = dict(model.named_parameters())
+    for k in ("mapping_matrix.similarity1.conv0.weight", "dres0.0.0.weight", "dres2.conv6.0.weight", "classif3.2.weight",
+              "feature_extraction.firstconv.0.0.weight", "feature_extraction.lastconv.2.weight", "dres4.conv5.1.bias"):
+        ref = float(g["gn_" + k.replace(".", "_")])
+        got = float(params[k].grad.norm())
+        assert abs(got - ref) <= 2e-2 * ref + 1e-7, (k, got, ref)
 
 
 def test_hot_path_batch2_q1(ecm, cmfsm_sd):

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Per-kernel timing at the SceneFlow shapes (576x960, D=192 -> 1/4-res volume [48,144,240]) on one MI355X.
+HIP-event timing on torch's current stream (the stream the kernels are launched on)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ecm_amd  # noqa: E402
+
+ops = ecm_amd.ops
+dev = "cuda"
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def report(name, ms, gbytes=None, gflop=None):
+    extra = ""
+    if gbytes:
+        extra += f"  {gbytes / ms:8.1f} GB/s ({gbytes / ms / 8000 * 100:.1f}% of 8 TB/s)"
+    if gflop:
+        extra += f"  {gflop / ms:8.2f} TFLOP/s ({gflop / ms / 157.3 * 100:.1f}% of 157.3)"
+    print(f"{name:44s} {ms:9.3f} ms{extra}", flush=True)
+
+
+def main():
+    torch.manual_seed(0)
+    B, h, w, D = 1, 144, 240, 48
+    L, R = torch.randn(B, 32, h, w, device=dev), torch.randn(B, 32, h, w, device=dev)
+    cost = ops.cost_volume(L, R, D)
+    vol_mb = cost.numel() * 4 / 1e6
+    report("costvol fwd 576x960 D=192", timeit(lambda: ops.cost_volume(L, R, D)), (vol_mb + 2 * L.numel() * 4 / 1e6))
+    g = torch.randn_like(cost)
+    report("costvol bwd 576x960", timeit(lambda: ops.CostVolumeConcat.backward(type("c", (), {"dims": (B, 32, h, w, D)}), g)),
+           (vol_mb + 2 * L.numel() * 4 / 1e6))
+    del g
+    L5, R5 = torch.randn(1, 32, 270, 480, device=dev), torch.randn(1, 32, 270, 480, device=dev)
+    c5 = ops.cost_volume(L5, R5, 64)
+    report("costvol fwd 1080x1920 D=256 (cfg5)", timeit(lambda: ops.cost_volume(L5, R5, 64)),
+           (c5.numel() * 4 + 2 * L5.numel() * 4) / 1e6)
+    del c5, L5, R5
+    torch.cuda.empty_cache()
+
+    V = D * h * w
+    for (ci, co, dims, st, label) in [(64, 32, (48, 144, 240), 1, "dres0.0"), (32, 32, (48, 144, 240), 1, "conv 32->32"),
+                                      (32, 64, (48, 144, 240), 2, "hg.conv1 s2"), (64, 64, (24, 72, 120), 1, "hg.conv2"),
+                                      (64, 64, (24, 72, 120), 2, "hg.conv3 s2"), (64, 64, (12, 36, 60), 1, "hg.conv4"),
+                                      (32, 1, (48, 144, 240), 1, "classif.2 (Co=1)")]:
+        x = torch.randn(B, ci, *dims, device=dev)
+        wt = torch.randn(co, ci, 3, 3, 3, device=dev) * 0.05
+        pk = ops._pack_conv(wt)
+        od = [(d - 1) // st + 1 for d in dims]
+        gf = 2.0 * 27 * ci * co * od[0] * od[1] * od[2] * B / 1e9
+        report(f"conv3d {label} {ci}->{co} s{st} {dims}", timeit(lambda: ops._conv_fwd(x, pk, co, st)), gflop=gf)
+    for (ci, co, dims, label) in [(64, 64, (12, 36, 60), "hg.conv5"), (64, 32, (24, 72, 120), "hg.conv6")]:
+        x = torch.randn(B, ci, *dims, device=dev)
+        wt = torch.randn(ci, co, 3, 3, 3, device=dev) * 0.05
+        pk = ops._pack_deconv(wt)
+        gf = 2.0 * 27 * ci * co * dims[0] * dims[1] * dims[2] * B / 1e9
+        report(f"deconv3d {label} {ci}->{co} {dims}", timeit(lambda: ops._deconv_fwd(x, pk, co, [2 * d for d in dims])), gflop=gf)
+
+    x = torch.randn(B, 32, D, h, w, device=dev)
+    gm, bt = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+    mb = x.numel() * 4 / 1e6
+    report("gn stats+apply(relu) 32ch volume", timeit(lambda: ops.group_norm_act(x, gm, bt, None, True)), 3 * mb)
+    report("gn stats+apply(relu,+skip)", timeit(lambda: ops.group_norm_act(x, gm, bt, x, True)), 4 * mb)
+
+    lr, hr = torch.randn(B, 32, h, w, device=dev), torch.randn(B, 32, 4 * h, 4 * w, device=dev)
+    W0, W1, W2, W3 = (torch.randn(*s, device=dev) * 0.2 for s in ((32, 66, 1, 1), (16, 32, 1, 1), (8, 16, 1, 1), (1, 8, 1, 1)))
+    report("ecm_weights9 fwd 576x960", timeit(lambda: ops.ecm_weights9(lr, hr, W0, W1, W2, W3)),
+           (hr.numel() + lr.numel() + 9 * 576 * 960) * 4 / 1e6, gflop=7.7)
+    c = torch.randn(3, B, D, h, w, device=dev)
+    report("softargmin 3 heads", timeit(lambda: ops.softargmin_heads(c)), c.numel() * 4 / 1e6)
+    d = ops.softargmin_heads(c)
+    w9 = torch.softmax(torch.randn(B, 9, 4 * h, 4 * w, device=dev), 1)
+    report("aggregate9 3 heads", timeit(lambda: ops.ecm_aggregate9(d, w9, 4)), (12 * 576 * 960) * 4 / 1e6)
+
+    model = ecm_amd.get_model("cmfsm").cuda().eval()
+    left, right = torch.randn(1, 3, 576, 960, device=dev), torch.randn(1, 3, 576, 960, device=dev)
+    with torch.no_grad():
+        lr_l, _, hr_l = model.feature_extraction(left)
+        lr_r, _, _ = model.feature_extraction(right)
+        report("encoder x2 (PyTorch/MIOpen)", timeit(lambda: (model.feature_extraction(left), model.feature_extraction(right)), 5, 2))
+        report("hot path fwd (HIP)", timeit(lambda: model.hot_path(lr_l, hr_l, lr_r), 5, 2), gflop=1069)
+        report("full cmfsm fwd 576x960", timeit(lambda: model(left, right), 5, 2))
+
+
+if __name__ == "__main__":
+    main()

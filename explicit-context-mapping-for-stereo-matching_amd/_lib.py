@@ -67,13 +67,37 @@ def missing_symbols():
     return [n for n in PROTOTYPES if not hasattr(lib, n)]
 
 
+# Optional per-launch timing (bench.py's roofline leg): name -> list of (start_event, end_event, int_args).
+# Events are recorded on torch's current stream, which is the stream every kernel is launched on.
+_timers = {}
+
+
+def enable_timer(name: str):
+    _timers[name] = []
+
+
+def disable_timers():
+    out = dict(_timers)
+    _timers.clear()
+    return out
+
+
 def call(name: str, *args):
     """Call an int-returning entry point and raise RuntimeError on a non-zero code."""
     lib = load()
     fn = getattr(lib, name, None)
     if fn is None:
         raise RuntimeError(f"libecm_hip.so does not export {name}")
-    rc = fn(*args)
+    rec = _timers.get(name)
+    if rec is not None:
+        import torch
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        rec.append((s, e, tuple(a for a in args if isinstance(a, int))))
+    else:
+        rc = fn(*args)
     if rc != 0:
         msg = lib.ecm_error_string(rc)
         raise RuntimeError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -32,21 +32,21 @@ struct ConvCfg {
     static constexpr int COP = CO_TILES * 32;
     static constexpr int XS_FLOATS = CIC * ID * IH * RS;
     static constexpr int WS_FLOATS = 27 * CIC * COP;
-    static constexpr int LDS_BYTES = (XS_FLOATS + WS_FLOATS) * 4;
+    static constexpr int LDS_BYTES = (XS_FLOATS + 2 * WS_FLOATS) * 4;     // weight slice is double-buffered (LDS-DMA)
     static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
     static_assert((NT <= TH && TH % NT == 0) || (NT % TH == 0), "wave rows must tile (dz,hy) statically");
     static_assert(CIC % 2 == 0, "k-step is 2 channels");
 };
 
 template <int CO_TILES, int STRIDE, int TD, int TH, int CIC>
-__global__ __launch_bounds__(256) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                       float* __restrict__ y, int Ci, int Co, int D, int H, int W,
                                                       int Do, int Ho, int Wo, int tiles_d, int tiles_h, int tiles_w) {
     using Cfg = ConvCfg<CO_TILES, STRIDE, TD, TH, CIC>;
     constexpr int ID = Cfg::ID, IH = Cfg::IH, IW = Cfg::IW, RS = Cfg::RS, NT = Cfg::NT, COP = Cfg::COP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [CIC][ID][IH][RS]
-    float* Ws = smem + Cfg::XS_FLOATS;      // [27][CIC][COP]
+    float* Ws = smem + Cfg::XS_FLOATS;      // 2 x [27][CIC][COP]
 
     // tile decode (x fastest so neighbouring workgroups share halo rows in L2)
     int bid = blockIdx.x;
@@ -77,28 +77,70 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma(const float* __restrict__ 
     const size_t HWi = (size_t)H * W, DHWi = (size_t)D * HWi;
     const float* xb = x + (size_t)b * Ci * DHWi;
 
-    for (int c0 = 0; c0 < Ci; c0 += CIC) {
-        __syncthreads();
-        // ---- stage the halo tile (zero padded) -------------------------------------------------
-        for (int e = tid; e < CIC * ID * IH * IW; e += 256) {
-            int t = e;
-            const int xx = t % IW; t /= IW;
-            const int hy = t % IH; t /= IH;
-            const int dz = t % ID;
-            const int cc = t / ID;
-            const int gz = id0 + dz, gy = ih0 + hy, gx = iw0 + xx;
-            float v = 0.f;
-            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = xb[(size_t)(c0 + cc) * DHWi + (size_t)gz * HWi + (size_t)gy * W + gx];
-            Xs[((cc * ID + dz) * IH + hy) * RS + xx] = v;
+    // Staging is software-pipelined through registers: the global loads of chunk c+1 are issued before the
+    // MFMA loop of chunk c and only waited for when they are written to LDS, so HBM/L2 latency hides under
+    // ~27k cycles of matrix work instead of being paid 32 times per chunk.
+    // Channel-major staging: a thread owns PP fixed (dz,hy,xx) positions of the 3-D halo window (offsets and bounds
+    // computed once per tile) and walks the CIC channel planes of a chunk, whose base addresses are wave-uniform.
+    constexpr int NPOS = ID * IH * IW;
+    constexpr int PP = (NPOS + 255) / 256;                         // positions per thread
+    constexpr int NX = CIC * PP;
+    constexpr int NWQ = (27 * CIC * COP / 4 + 255) / 256;          // weight float4s per thread
+    float xr[NX];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // Loads go through buffer descriptors (one per channel plane, built from wave-uniform scalars): 32-bit per-lane
+    // byte offsets, and the hardware range check returns 0 for the 0x80000000 offset given to every position outside
+    // the volume -- zero padding costs no compare, no select and no 64-bit address math.
+    unsigned posoff[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+        const int p = tid + j * 256;
+        int t = p;
+        const int xx = t % IW; t /= IW;
+        const int hy = t % IH;
+        const int dz = t / IH;
+        const int gz = id0 + dz, gy = ih0 + hy, gx = iw0 + xx;
+        const bool ok = p < NPOS && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        posoff[j] = ok ? (unsigned)(gz * (int)HWi + gy * W + gx) * 4u : 0x80000000u;
+    }
+    const unsigned plane_bytes = (unsigned)DHWi * 4u;
+    auto prefetch = [&](int c0, float* wdst) {
+        // weight slice: global -> LDS directly (global_load_lds_dwordx4: no VGPRs, lands at wave base + lane*16)
+#pragma unroll
+        for (int i = 0; i < NWQ; ++i) {
+            const int e = tid + i * 256;
+            if (e < 27 * CIC * COP / 4) {
+                const int tap = e / (CIC * COP / 4), r = e - tap * (CIC * COP / 4);
+                const float* src = wp + ((size_t)tap * Ci + c0) * COP + (size_t)r * 4;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wdst + (wave_u * 64 + i * 256) * 4), 16, 0, 0);
+            }
         }
-        // ---- stage the weight slice [27][CIC][COP] (packed global layout [27][Ci][COP]) --------
-        for (int e = tid; e < 27 * CIC * COP / 4; e += 256) {
-            const int tap = e / (CIC * COP / 4), r = e - tap * (CIC * COP / 4);
-            reinterpret_cast<float4*>(Ws)[e] =
-                reinterpret_cast<const float4*>(wp + ((size_t)tap * Ci + c0) * COP)[r];
+#pragma unroll
+        for (int cc = 0; cc < CIC; ++cc) {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(c0 + cc) * DHWi), 0,
+                                                                plane_bytes, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < PP; ++j)
+                xr[cc * PP + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, posoff[j], 0, 0));
         }
+    };
+    prefetch(0, Ws);
+    int buf = 0;
+    for (int c0 = 0; c0 < Ci; c0 += CIC, buf ^= 1) {
+        __syncthreads();                                   // previous chunk's LDS reads are done
+#pragma unroll
+        for (int cc = 0; cc < CIC; ++cc)
+#pragma unroll
+            for (int j = 0; j < PP; ++j) {
+                const int p = tid + j * 256;
+                if (p < NPOS) Xs[cc * NPOS + p] = xr[cc * PP + j];          // [cc][dz][hy][xx], RS == IW
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight DMA for this chunk has landed
         __syncthreads();
+        const float* Wc = Ws + buf * Cfg::WS_FLOATS;
+        if (c0 + CIC < Ci) prefetch(c0 + CIC, Ws + (buf ^ 1) * Cfg::WS_FLOATS);   // in flight during the MFMA loop below
         // ---- 27 * CIC/2 k-steps ---------------------------------------------------------------
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
@@ -108,7 +150,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma(const float* __restrict__ 
             for (int kk = 0; kk < CIC / 2; ++kk) {
                 float a[CO_TILES];
 #pragma unroll
-                for (int ct = 0; ct < CO_TILES; ++ct) a[ct] = Ws[wbase + (tap * CIC + kk * 2) * COP + ct * 32];
+                for (int ct = 0; ct < CO_TILES; ++ct) a[ct] = Wc[wbase + (tap * CIC + kk * 2) * COP + ct * 32];
 #pragma unroll
                 for (int r = 0; r < NT; ++r) {
                     const int dz = (NT <= TH) ? 0 : r / TH;
@@ -168,7 +210,7 @@ int launch_conv(const float* x, const float* wp, float* y, int B, int Ci, int Co
     const int Do = (D - 1) / STRIDE + 1, Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
     const int tiles_d = (Do + TD - 1) / TD, tiles_h = (Ho + TH - 1) / TH, tiles_w = (Wo + TW - 1) / TW;
     const long long nblk = (long long)B * tiles_d * tiles_h * tiles_w;
-    if (nblk > 0x7fffffffLL) return ECM_EUNSUP;
+    if (nblk > 0x7fffffffLL || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
     auto kern = conv3d_k3_mfma<CO_TILES, STRIDE, TD, TH, CIC>;
     static bool attr_set = false;       // benign race: same value every time
     if (!attr_set) {

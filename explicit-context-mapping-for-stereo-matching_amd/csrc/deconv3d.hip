@@ -65,26 +65,56 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma(const float* __restric
     const float* xb = x + (size_t)b * Ci * DHWi;
     const int nd = 1 + pd, nh = 1 + ph, nw = 1 + pw;     // taps per dimension for this class
 
-    for (int c0 = 0; c0 < Ci; c0 += CIC) {
-        __syncthreads();
-        for (int e = tid; e < CIC * ID * IH * IW; e += 256) {
+    // register-pipelined staging (see conv3d.hip): loads of chunk c+1 fly under the MFMAs of chunk c
+    constexpr int NX = (CIC * ID * IH * IW + 255) / 256;
+    constexpr int NWQ = (27 * CIC * COP / 4 + 255) / 256;
+    float xr[NX];
+    float4 wr[NWQ];
+    unsigned okmask = 0;              // bit i: element i is inside the volume (masking is deferred to the LDS write,
+                                      // so nothing consumes a load result before the MFMA loop)
+    static_assert(NX <= 32, "okmask is 32 bits");
+    auto prefetch = [&](int c0) {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tv + i * 256;
             int t = e;
             const int xx = t % IW; t /= IW;
             const int hy = t % IH; t /= IH;
             const int dz = t % ID;
             const int cc = t / ID;
             const int gz = md0 + dz, gy = mh0 + hy, gx = mw0 + xx;
-            float v = 0.f;
-            if (gz < D && gy < H && gx < W)
-                v = xb[(size_t)(c0 + cc) * DHWi + (size_t)gz * HWi + (size_t)gy * W + gx];
-            Xs[((cc * ID + dz) * IH + hy) * RS + xx] = v;
+            const bool ok = e < CIC * ID * IH * IW && gz < D && gy < H && gx < W;
+            const int off = ok ? (c0 + cc) * (int)DHWi + gz * (int)HWi + gy * W + gx : 0;
+            xr[i] = xb[off];
+            m |= (ok ? 1u : 0u) << i;
         }
-        for (int e = tid; e < 27 * CIC * COP / 4; e += 256) {
-            const int tap = e / (CIC * COP / 4), r = e - tap * (CIC * COP / 4);
-            reinterpret_cast<float4*>(Ws)[e] =
-                reinterpret_cast<const float4*>(wp + ((size_t)tap * Ci + c0) * COP)[r];
+        okmask = m;
+#pragma unroll
+        for (int i = 0; i < NWQ; ++i) {
+            const int e = tv + i * 256;
+            const int ec = e < 27 * CIC * COP / 4 ? e : 0;
+            const int tap = ec / (CIC * COP / 4), r = ec - tap * (CIC * COP / 4);
+            wr[i] = reinterpret_cast<const float4*>(wp + ((size_t)tap * Ci + c0) * COP)[r];
+        }
+    };
+    prefetch(0);
+    for (int c0 = 0; c0 < Ci; c0 += CIC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + i * 256;
+            if (e < CIC * ID * IH * IW) Xs[e] = (okmask >> i) & 1u ? xr[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NWQ; ++i) {
+            const int e = tid + i * 256;
+            if (e < 27 * CIC * COP / 4) reinterpret_cast<float4*>(Ws)[e] = wr[i];
         }
         __syncthreads();
+        if (c0 + CIC < Ci) prefetch(c0 + CIC);
         for (int a_d = 0; a_d < nd; ++a_d) {
             const int kd = pd ? (a_d ? 0 : 2) : 1, sd = a_d;          // tap index, input offset (+0 / +1)
             for (int a_h = 0; a_h < nh; ++a_h) {
@@ -148,7 +178,7 @@ int launch_deconv(const float* x, const float* wp, float* y, int B, int Ci, int 
     using Cfg = DeconvCfg<CO_TILES, TD, TH, CIC>;
     const int tiles_d = (D + TD - 1) / TD, tiles_h = (H + TH - 1) / TH, tiles_w = (W + TW - 1) / TW;
     const long long nblk = 8LL * B * tiles_d * tiles_h * tiles_w;
-    if (nblk > 0x7fffffffLL) return ECM_EUNSUP;
+    if (nblk > 0x7fffffffLL || (long long)Ci * D * H * W > 0x7fffffffLL) return ECM_EUNSUP;
     auto kern = deconv3d_k3s2_mfma<CO_TILES, TD, TH, CIC>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [which]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ecm_amd
+ops = ecm_amd.ops
+which = sys.argv[1] if len(sys.argv) > 1 else "conv"
+dev = "cuda"
+B = 1
+if which == "conv":
+    x = torch.randn(B, 32, 48, 144, 240, device=dev); w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
+    pk = ops._pack_conv(w)
+    for _ in range(5): y = ops._conv_fwd(x, pk, 32, 1)
+elif which == "wgrad":
+    x = torch.randn(B, 32, 48, 144, 240, device=dev); gy = torch.randn(B, 32, 48, 144, 240, device=dev)
+    for _ in range(5): g = ops._wgrad(x, gy, 32, 32, 1)
+elif which == "costvol":
+    L, R = torch.randn(B, 32, 144, 240, device=dev), torch.randn(B, 32, 144, 240, device=dev)
+    for _ in range(5): c = ops.cost_volume(L, R, 48)
+torch.cuda.synchronize()

@@ -72,6 +72,15 @@ def main():
         gf = 2.0 * 27 * ci * co * dims[0] * dims[1] * dims[2] * B / 1e9
         report(f"deconv3d {label} {ci}->{co} {dims}", timeit(lambda: ops._deconv_fwd(x, pk, co, [2 * d for d in dims])), gflop=gf)
 
+    for (ci, co, dims, st, label) in [(32, 32, (48, 144, 240), 1, "wgrad 32->32"), (64, 32, (48, 144, 240), 1, "wgrad dres0.0"),
+                                      (32, 64, (48, 144, 240), 2, "wgrad hg.conv1 s2"), (64, 64, (24, 72, 120), 1, "wgrad hg.conv2"),
+                                      (64, 64, (24, 72, 120), 2, "wgrad hg.conv3 s2"), (64, 64, (12, 36, 60), 1, "wgrad hg.conv4")]:
+        x = torch.randn(B, ci, *dims, device=dev)
+        od = [(d - 1) // st + 1 for d in dims]
+        gy = torch.randn(B, co, *od, device=dev)
+        gf = 2.0 * 27 * ci * co * od[0] * od[1] * od[2] * B / 1e9
+        report(f"{label} {ci}->{co} s{st} {dims}", timeit(lambda: ops._wgrad(x, gy, co, ci, st)), gflop=gf)
+    del x, gy
     x = torch.randn(B, 32, D, h, w, device=dev)
     gm, bt = torch.ones(32, device=dev), torch.zeros(32, device=dev)
     mb = x.numel() * 4 / 1e6

@@ -33,32 +33,41 @@ struct WgCfg {
 
 
 // One staged tile: TD*TH*TWV/2 k-steps (two x-adjacent voxels each), taps [T0, T0+7) of this wave.
+// The LDS operands of k-step i+1 are read before the MFMAs of k-step i are issued (explicit register double
+// buffer), so with one wave per SIMD the ~100-cycle ds_read latency hides under 7 x 64 cycles of matrix work.
 template <int STRIDE, int TD, int TH, int T0>
 __device__ __forceinline__ void wg_tile(const float* __restrict__ ga, const float* __restrict__ xb, f32x16 (&acc)[7]) {
     using Cfg = WgCfg<STRIDE, TD, TH>;
     constexpr int IH = Cfg::IH, RS = Cfg::RS;
+    constexpr int NT = (T0 + 7 <= 27) ? 7 : 27 - T0;          // taps of this wave (the last wave has 6)
+    constexpr int KS = TD * TH * TWV / 2;
+    auto a_off = [](int ks) constexpr { return ks * 2; };     // voxel index of the pair: (dz*TH+hy)*TWV + xx == 2*ks
+    auto b_off = [](int ks, int t) constexpr {
+        const int xx = (ks * 2) % TWV, hy = ((ks * 2) / TWV) % TH, dz = (ks * 2) / (TWV * TH);
+        const int tap = T0 + t, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        return ((dz * STRIDE + kd) * IH + hy * STRIDE + kh) * RS + xx * STRIDE + kw;
+    };
+    float a_cur = ga[a_off(0)], b_cur[NT];
 #pragma unroll
-    for (int dz = 0; dz < TD; ++dz)
+    for (int t = 0; t < NT; ++t) b_cur[t] = xb[b_off(0, t)];
 #pragma unroll
-        for (int hy = 0; hy < TH; ++hy)
+    for (int ks = 0; ks < KS; ++ks) {
+        float a_nxt = 0.f, b_nxt[NT];
+        if (ks + 1 < KS) {
+            a_nxt = ga[a_off(ks + 1)];
 #pragma unroll
-            for (int xx = 0; xx < TWV; xx += 2) {
-                const float a = ga[(dz * TH + hy) * TWV + xx];
+            for (int t = 0; t < NT; ++t) b_nxt[t] = xb[b_off(ks + 1, t)];
+        }
 #pragma unroll
-                for (int t = 0; t < 7; ++t) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int tap = T0 + t;
-                    if (tap < 27) {                       // tap 27 (last wave, t = 6) does not exist
-                        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                        const float bv = xb[((dz * STRIDE + kd) * IH + hy * STRIDE + kh) * RS + xx * STRIDE + kw];
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
-                    }
-                }
-            }
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b_cur[t] = b_nxt[t];
+    }
 }
 
 template <int STRIDE, int TD, int TH>
-__global__ __launch_bounds__(256, 2) void conv3d_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
+__global__ __launch_bounds__(256, 1) void conv3d_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
                                                          float* __restrict__ partial, int B, int Ci, int Co, int D,
                                                          int H, int W, int Do, int Ho, int Wo, int tiles_d, int tiles_h,
                                                          int tiles_w, int ci_tiles) {
@@ -83,7 +92,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_mfma(const float* __restr
     const size_t HWo = (size_t)Ho * Wo, DHWo = (size_t)Do * HWo;
     const long long ntiles = (long long)B * tiles_d * tiles_h * tiles_w;
 
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Register-pipelined staging through buffer descriptors (see conv3d.hip): the loads of the NEXT tile are issued
+    // before this tile's MFMA loop; positions outside the volume carry offset 0x80000000 and read back as 0.
+    constexpr int NPOSX = ID * IH * IW;
+    constexpr int PPX = (NPOSX + 255) / 256;                 // x positions per thread per channel
+    constexpr int GPL = 256 / NV;                            // gy channels covered by one 256-thread pass
+    static_assert(256 % NV == 0 && CT % GPL == 0, "gy tile must divide the workgroup");
+    constexpr int NGRP = CT / GPL;
+    float xr[CT * PPX], gr[NGRP];
+    const unsigned xplane = (unsigned)DHWi * 4u, gplane = (unsigned)DHWo * 4u;
+    auto prefetch = [&](long long tile) {
         long long r = tile;
         const int tw = (int)(r % tiles_w); r /= tiles_w;
         const int th = (int)(r % tiles_h); r /= tiles_h;
@@ -91,31 +109,56 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_mfma(const float* __restr
         const int b = (int)(r / tiles_d);
         const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TWV;
         const int id0 = od0 * STRIDE - 1, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
-        __syncthreads();
-        // ---- stage x halo tile for 32 input channels (zero padded, zero for ci >= Ci) ------------------
-        for (int e = tid; e < CT * ID * IH * IW; e += 256) {
-            int t = e;
+        unsigned xoff[PPX];
+#pragma unroll
+        for (int j = 0; j < PPX; ++j) {
+            const int p = tid + j * 256;
+            int t = p;
             const int xx = t % IW; t /= IW;
-            const int hy = t % IH; t /= IH;
-            const int dz = t % ID;
-            const int cc = t / ID;
+            const int hy = t % IH;
+            const int dz = t / IH;
             const int gz = id0 + dz, gyy = ih0 + hy, gx = iw0 + xx;
-            float v = 0.f;
-            if (ci0 + cc < Ci && gz >= 0 && gz < D && gyy >= 0 && gyy < H && gx >= 0 && gx < W)
-                v = x[((size_t)b * Ci + ci0 + cc) * DHWi + (size_t)gz * HWi + (size_t)gyy * W + gx];
-            Xs[cc * XSTR + (dz * IH + hy) * RS + xx] = v;
+            const bool ok = p < NPOSX && (unsigned)gz < (unsigned)D && (unsigned)gyy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            xoff[j] = ok ? (unsigned)(gz * (int)HWi + gyy * W + gx) * 4u : 0x80000000u;
         }
-        // ---- stage gy tile for 32 output channels (zero outside the volume / for co >= Co) -------------
-        for (int e = tid; e < CT * NV; e += 256) {
-            const int v = e % NV, cc = e / NV;
-            const int xx = v % TWV, hy = (v / TWV) % TH, dz = v / (TWV * TH);
-            const int od = od0 + dz, oh = oh0 + hy, ow = ow0 + xx;
-            float g = 0.f;
-            if (co0 + cc < Co && od < Do && oh < Ho && ow < Wo)
-                g = gy[((size_t)b * Co + co0 + cc) * DHWo + (size_t)od * HWo + (size_t)oh * Wo + ow];
-            Gs[cc * GSTR + v] = g;
-        }
+        // ONE descriptor per tensor and sample; the (uniform) channel offset is added to the per-lane offset.  The
+        // out-of-volume marker 0x80000000 stays >= num_records after adding any channel offset (< 2^31 bytes per sample).
+        const int nci = Ci - ci0 < CT ? Ci - ci0 : CT, nco = Co - co0 < CT ? Co - co0 : CT;
+        const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + ((size_t)b * Ci + ci0) * DHWi), 0,
+                                                           (unsigned)nci * xplane, 0x00020000);
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+            for (int j = 0; j < PPX; ++j)
+                xr[cc * PPX + j] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[j] + (unsigned)cc * xplane, 0, 0));
+        // gy: thread -> (channel within group = tid / NV, voxel = tid % NV)
+        const int v = tid % NV, ccl = tid / NV;
+        const int xx = v % TWV, hy = (v / TWV) % TH, dz = v / (TWV * TH);
+        const int od = od0 + dz, oh = oh0 + hy, ow = ow0 + xx;
+        const bool vok = od < Do && oh < Ho && ow < Wo;
+        const unsigned goff = vok ? (unsigned)(od * (int)HWo + oh * Wo + ow) * 4u + (unsigned)ccl * gplane : 0x80000000u;
+        const auto grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy + ((size_t)b * Co + co0) * DHWo), 0,
+                                                           (unsigned)nco * gplane, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g)
+            gr[g] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(grs, goff + (unsigned)(g * GPL) * gplane, 0, 0));
+    };
+    if ((long long)blockIdx.x < ntiles) prefetch(blockIdx.x);
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+            for (int j = 0; j < PPX; ++j) {
+                const int p = tid + j * 256;
+                if (p < NPOSX) Xs[cc * XSTR + p] = xr[cc * PPX + j];       // [ci][dz][hy][xx], odd channel stride
+            }
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) Gs[(g * GPL + tid / NV) * GSTR + tid % NV] = gr[g];
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
         const float* ga = Gs + l31 * GSTR + half;
         const float* xb = Xs + l31 * XSTR + half * STRIDE;
         switch (wave) {          // wave-uniform: makes every tap offset a compile-time immediate
@@ -150,7 +193,7 @@ __global__ void wgrad_reduce(const float* __restrict__ partial, float* __restric
 
 inline int wgrad_workers(int Ci, int Co, long long ntiles) {
     const int ytiles = ((Ci + CT - 1) / CT) * ((Co + CT - 1) / CT);
-    long long p = 512 / ytiles;                 // ~2 workgroups per CU in total
+    long long p = 256 / ytiles;                 // one persistent workgroup per CU in total (the kernel runs 1 block/CU)
     if (p < 1) p = 1;
     if (p > ntiles) p = ntiles;
     return (int)p;
@@ -182,7 +225,7 @@ int launch_wgrad(const float* x, const float* gy, float* gw, float* partial, int
 
 inline long long ntiles_for(int B, int D, int H, int W, int stride) {
     const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    const int TD = stride == 1 ? 2 : 1, TH = stride == 1 ? 4 : 2;
+    const int TD = stride == 1 ? 2 : 1, TH = stride == 1 ? 8 : 4;
     return (long long)B * ((Do + TD - 1) / TD) * ((Ho + TH - 1) / TH) * ((Wo + TWV - 1) / TWV);
 }
 
@@ -197,9 +240,10 @@ extern "C" int ecm_conv3d_k3_wgrad(const float* x, const float* gy, float* gw, v
                                    int B, int Ci, int Co, int D, int H, int W, int stride, void* stream) {
     ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0);
     if (stride != 1 && stride != 2) return ECM_EUNSUP;
+    if ((long long)D * H * W * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;  // 32-bit buffer offsets over a 32-channel tile
     if (scratch_bytes < ecm_conv3d_wgrad_scratch_bytes(B, Ci, Co, D, H, W, stride)) return ECM_ESCRATCH;
     float* partial = static_cast<float*>(scratch);
     hipStream_t st = ecm_stream(stream);
-    if (stride == 1) return launch_wgrad<1, 2, 4>(x, gy, gw, partial, B, Ci, Co, D, H, W, st);
-    return launch_wgrad<2, 1, 2>(x, gy, gw, partial, B, Ci, Co, D, H, W, st);
+    if (stride == 1) return launch_wgrad<1, 2, 8>(x, gy, gw, partial, B, Ci, Co, D, H, W, st);
+    return launch_wgrad<2, 1, 4>(x, gy, gw, partial, B, Ci, Co, D, H, W, st);
 }

@@ -21,13 +21,13 @@ struct DeconvCfg {
     static constexpr int NT = TD * TH / 4;
     static constexpr int COP = CO_TILES * 32;
     static constexpr int XS_FLOATS = CIC * ID * IH * RS;
-    static constexpr int WS_FLOATS = 27 * CIC * COP;
-    static constexpr int LDS_BYTES = (XS_FLOATS + WS_FLOATS) * 4;
+    static constexpr int WS_FLOATS = 8 * CIC * COP;                 // one parity class uses at most 8 taps
+    static constexpr int LDS_BYTES = (XS_FLOATS + 2 * WS_FLOATS) * 4;
     static_assert((TD * TH) % 4 == 0 && NT <= TH && TH % NT == 0, "tile/wave split");
 };
 
 template <int CO_TILES, int TD, int TH, int CIC>
-__global__ __launch_bounds__(256) void deconv3d_k3s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, 2) void deconv3d_k3s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                           float* __restrict__ y, int Ci, int Co, int D, int H, int W,
                                                           int Do, int Ho, int Wo, int tiles_d, int tiles_h,
                                                           int tiles_w) {
@@ -65,64 +65,76 @@ __global__ __launch_bounds__(256) void deconv3d_k3s2_mfma(const float* __restric
     const float* xb = x + (size_t)b * Ci * DHWi;
     const int nd = 1 + pd, nh = 1 + ph, nw = 1 + pw;     // taps per dimension for this class
 
-    // register-pipelined staging (see conv3d.hip): loads of chunk c+1 fly under the MFMAs of chunk c
-    constexpr int NX = (CIC * ID * IH * IW + 255) / 256;
-    constexpr int NWQ = (27 * CIC * COP / 4 + 255) / 256;
+    // Staging as in conv3d.hip: halo tile through registers with buffer-descriptor loads (hardware zero fill for
+    // positions beyond the input), this class's taps only ( <= 8 of the 27) by LDS-DMA into a double buffer.
+    constexpr int NPOS = ID * IH * IW;
+    constexpr int PP = (NPOS + 255) / 256;
+    constexpr int NX = CIC * PP;
+    constexpr int WSLICE = CIC * COP;                              // floats per tap per chunk
+    constexpr int NWQ = (8 * WSLICE / 4 + 255) / 256;
     float xr[NX];
-    float4 wr[NWQ];
-    unsigned okmask = 0;              // bit i: element i is inside the volume (masking is deferred to the LDS write,
-                                      // so nothing consumes a load result before the MFMA loop)
-    static_assert(NX <= 32, "okmask is 32 bits");
-    auto prefetch = [&](int c0) {
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-        unsigned m = 0;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int ntaps = nd * nh * nw;
+    unsigned posoff[PP];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int e = tv + i * 256;
-            int t = e;
-            const int xx = t % IW; t /= IW;
-            const int hy = t % IH; t /= IH;
-            const int dz = t % ID;
-            const int cc = t / ID;
-            const int gz = md0 + dz, gy = mh0 + hy, gx = mw0 + xx;
-            const bool ok = e < CIC * ID * IH * IW && gz < D && gy < H && gx < W;
-            const int off = ok ? (c0 + cc) * (int)DHWi + gz * (int)HWi + gy * W + gx : 0;
-            xr[i] = xb[off];
-            m |= (ok ? 1u : 0u) << i;
-        }
-        okmask = m;
+    for (int j = 0; j < PP; ++j) {
+        const int p = tid + j * 256;
+        int t = p;
+        const int xx = t % IW; t /= IW;
+        const int hy = t % IH;
+        const int dz = t / IH;
+        const int gz = md0 + dz, gy = mh0 + hy, gx = mw0 + xx;
+        const bool ok = p < NPOS && gz < D && gy < H && gx < W;
+        posoff[j] = ok ? (unsigned)(gz * (int)HWi + gy * W + gx) * 4u : 0x80000000u;
+    }
+    const unsigned plane_bytes = (unsigned)DHWi * 4u;
+    auto prefetch = [&](int c0, float* wdst) {
 #pragma unroll
         for (int i = 0; i < NWQ; ++i) {
-            const int e = tv + i * 256;
-            const int ec = e < 27 * CIC * COP / 4 ? e : 0;
-            const int tap = ec / (CIC * COP / 4), r = ec - tap * (CIC * COP / 4);
-            wr[i] = reinterpret_cast<const float4*>(wp + ((size_t)tap * Ci + c0) * COP)[r];
+            const int e = tid + i * 256;
+            const int lt = e / (WSLICE / 4), r = e - lt * (WSLICE / 4);         // local tap index (a_d, a_h, a_w)
+            if (lt < ntaps) {
+                const int a_w = lt % nw, a_h = (lt / nw) % nh, a_d = lt / (nw * nh);
+                const int kd = pd ? (a_d ? 0 : 2) : 1, kh = ph ? (a_h ? 0 : 2) : 1, kw = pw ? (a_w ? 0 : 2) : 1;
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                const float* src = wp + ((size_t)tap * Ci + c0) * COP + (size_t)r * 4;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wdst + (wave_u * 64 + i * 256) * 4), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CIC; ++cc) {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(c0 + cc) * DHWi), 0,
+                                                                plane_bytes, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < PP; ++j)
+                xr[cc * PP + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, posoff[j], 0, 0));
         }
     };
-    prefetch(0);
-    for (int c0 = 0; c0 < Ci; c0 += CIC) {
+    prefetch(0, Ws);
+    int buf = 0;
+    for (int c0 = 0; c0 < Ci; c0 += CIC, buf ^= 1) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int e = tid + i * 256;
-            if (e < CIC * ID * IH * IW) Xs[e] = (okmask >> i) & 1u ? xr[i] : 0.f;
-        }
+        for (int cc = 0; cc < CIC; ++cc)
 #pragma unroll
-        for (int i = 0; i < NWQ; ++i) {
-            const int e = tid + i * 256;
-            if (e < 27 * CIC * COP / 4) reinterpret_cast<float4*>(Ws)[e] = wr[i];
-        }
+            for (int j = 0; j < PP; ++j) {
+                const int p = tid + j * 256;
+                if (p < NPOS) Xs[cc * NPOS + p] = xr[cc * PP + j];
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (c0 + CIC < Ci) prefetch(c0 + CIC);
+        const float* Wc = Ws + buf * (8 * WSLICE);
+        if (c0 + CIC < Ci) prefetch(c0 + CIC, Ws + (buf ^ 1) * (8 * WSLICE));
+        int lt = 0;
         for (int a_d = 0; a_d < nd; ++a_d) {
-            const int kd = pd ? (a_d ? 0 : 2) : 1, sd = a_d;          // tap index, input offset (+0 / +1)
+            const int sd = a_d;                                   // input offset (+0 / +1) of this tap
             for (int a_h = 0; a_h < nh; ++a_h) {
-                const int kh = ph ? (a_h ? 0 : 2) : 1, sh = a_h;
-                for (int a_w = 0; a_w < nw; ++a_w) {
-                    const int kw = pw ? (a_w ? 0 : 2) : 1, sw = a_w;
-                    const int tap = (kd * 3 + kh) * 3 + kw;
-                    const float* wt = Ws + wbase + tap * CIC * COP;
+                const int sh = a_h;
+                for (int a_w = 0; a_w < nw; ++a_w, ++lt) {
+                    const int sw = a_w;
+                    const float* wt = Wc + wbase + lt * WSLICE;
                     const float* xt = Xs + xbase + (sd * IH + sh) * RS + sw;
 #pragma unroll
                     for (int kk = 0; kk < CIC / 2; ++kk) {
@@ -178,7 +190,7 @@ int launch_deconv(const float* x, const float* wp, float* y, int B, int Ci, int 
     using Cfg = DeconvCfg<CO_TILES, TD, TH, CIC>;
     const int tiles_d = (D + TD - 1) / TD, tiles_h = (H + TH - 1) / TH, tiles_w = (W + TW - 1) / TW;
     const long long nblk = 8LL * B * tiles_d * tiles_h * tiles_w;
-    if (nblk > 0x7fffffffLL || (long long)Ci * D * H * W > 0x7fffffffLL) return ECM_EUNSUP;
+    if (nblk > 0x7fffffffLL || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
     auto kern = deconv3d_k3s2_mfma<CO_TILES, TD, TH, CIC>;
     static bool attr_set = false;
     if (!attr_set) {

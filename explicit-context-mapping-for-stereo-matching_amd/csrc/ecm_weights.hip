@@ -18,10 +18,34 @@ constexpr int CF = 32;                 // feature channels
 constexpr int TX = 64, TY = 4;         // pixels per workgroup: 4 rows x 64 cols, one wave per row
 constexpr int ASTRIDE = 36;            // padded cell stride in LDS (floats): 36c mod 64 spreads ds_read_b128
 
-__constant__ int kDy9[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
-__constant__ int kDx9[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
-// table used by plane n in forward(): 5..8 alias 1..4 (cmfsm.py:459-462, quirk Q2)
-__constant__ int kTab9[9] = {0, 1, 2, 3, 4, 1, 2, 3, 4};
+// Neighbour sets.  VAR 0: eight_related (cmfsm.py:431-593): 9 planes c,l,r,t,b,lt,rt,lb,rb; tables 0,1,2,3,4,1,2,3,4
+//   (5..8 alias 1..4, cmfsm.py:459-462, quirk Q2); out-of-image logit -100; output softmax.
+// VAR 1: six_related, reference image (cmfsm_sub_8.py:449-572): 5 planes c,r,l,t,b with tables 0,1,2,3,4
+//   (right uses table 1, left table 2: cmfsm_sub_8.py:503,525); out-of-image logit 0 (still in the softmax);
+//   extra LeakyReLU after conv3 (:318,342); output softmax*logit (:572).
+// VAR 2: six_related, target image: 3 planes c,r,l (cmfsm_sub_8.py:483-536), same MLP on the right-image features.
+template <int VAR> struct Nbr;
+template <> struct Nbr<0> {
+    static constexpr int N = 9; static constexpr bool FINAL_ACT = false, TIMES_LOGIT = false;
+    static constexpr float PAD = -100.f;
+    static __device__ __forceinline__ int dy(int n) { constexpr int t[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1}; return t[n]; }
+    static __device__ __forceinline__ int dx(int n) { constexpr int t[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1}; return t[n]; }
+    static __device__ __forceinline__ int tab(int n) { constexpr int t[9] = {0, 1, 2, 3, 4, 1, 2, 3, 4}; return t[n]; }
+};
+template <> struct Nbr<1> {
+    static constexpr int N = 5; static constexpr bool FINAL_ACT = true, TIMES_LOGIT = true;
+    static constexpr float PAD = 0.f;
+    static __device__ __forceinline__ int dy(int n) { constexpr int t[5] = {0, 0, 0, -1, 1}; return t[n]; }
+    static __device__ __forceinline__ int dx(int n) { constexpr int t[5] = {0, 1, -1, 0, 0}; return t[n]; }
+    static __device__ __forceinline__ int tab(int n) { constexpr int t[5] = {0, 1, 2, 3, 4}; return t[n]; }
+};
+template <> struct Nbr<2> {
+    static constexpr int N = 3; static constexpr bool FINAL_ACT = true, TIMES_LOGIT = true;
+    static constexpr float PAD = 0.f;
+    static __device__ __forceinline__ int dy(int n) { return 0; }
+    static __device__ __forceinline__ int dx(int n) { constexpr int t[3] = {0, 1, -1}; return t[n]; }
+    static __device__ __forceinline__ int tab(int n) { constexpr int t[3] = {0, 1, 2}; return t[n]; }
+};
 
 __device__ __forceinline__ float centre_pat(int r, int s) { return (float)(r < s / 2 ? r - s / 2 : r - s / 2 + 1); }
 // offset channel 0 (varies with X) / channel 1 (varies with Y) of table t at in-cell position r
@@ -81,7 +105,8 @@ __device__ __forceinline__ float mlp_tail(const float (&h0)[CF], const float* __
     return FINAL_ACT ? leaky(o) : o;
 }
 
-__global__ __launch_bounds__(256) void ecm_weights9_fwd_kernel(const float* __restrict__ A, const float* __restrict__ hr,
+template <int VAR>
+__global__ __launch_bounds__(256) void ecm_weights_fwd_kernel(const float* __restrict__ A, const float* __restrict__ hr,
                                                                const float* __restrict__ W0, const float* __restrict__ W1,
                                                                const float* __restrict__ W2, const float* __restrict__ W3,
                                                                float* __restrict__ w9, int h, int w, int s) {
@@ -117,12 +142,14 @@ __global__ __launch_bounds__(256) void ecm_weights9_fwd_kernel(const float* __re
         Bv[j] = acc;
     }
     const int cy = Y / s, cx = X / s, ry = Y - cy * s, rx = X - cx * s;
-    float logit[9];
+    using NB = Nbr<VAR>;
+    constexpr int NN = NB::N;
+    float logit[NN];
 #pragma unroll
-    for (int n = 0; n < 9; ++n) {
-        const int yy = cy + kDy9[n], xx = cx + kDx9[n];
-        if (yy < 0 || yy >= h || xx < 0 || xx >= w) { logit[n] = -100.f; continue; }     // cmfsm.py:451-452
-        const float ox = off_x(kTab9[n], rx, s), oy = off_y(kTab9[n], ry, s);
+    for (int n = 0; n < NN; ++n) {
+        const int yy = cy + NB::dy(n), xx = cx + NB::dx(n);
+        if (yy < 0 || yy >= h || xx < 0 || xx >= w) { logit[n] = NB::PAD; continue; }     // cmfsm.py:451-452 / sub_8:461-462
+        const float ox = off_x(NB::tab(n), rx, s), oy = off_y(NB::tab(n), ry, s);
         const float* a = As + ((yy - cy0) * ncx + (xx - cx0)) * ASTRIDE;
         float h0[CF];
 #pragma unroll
@@ -133,18 +160,18 @@ __global__ __launch_bounds__(256) void ecm_weights9_fwd_kernel(const float* __re
             h0[j + 2] = leaky(fmaf(W0[(j + 2) * 66 + 65], oy, fmaf(W0[(j + 2) * 66 + 64], ox, av.z + Bv[j + 2])));
             h0[j + 3] = leaky(fmaf(W0[(j + 3) * 66 + 65], oy, fmaf(W0[(j + 3) * 66 + 64], ox, av.w + Bv[j + 3])));
         }
-        logit[n] = mlp_tail<false>(h0, W1, W2, W3);
+        logit[n] = mlp_tail<NB::FINAL_ACT>(h0, W1, W2, W3);
     }
     float m = logit[0];
 #pragma unroll
-    for (int n = 1; n < 9; ++n) m = fmaxf(m, logit[n]);
-    float e[9], sum = 0.f;
+    for (int n = 1; n < NN; ++n) m = fmaxf(m, logit[n]);
+    float e[NN], sum = 0.f;
 #pragma unroll
-    for (int n = 0; n < 9; ++n) { e[n] = expf(logit[n] - m); sum += e[n]; }
+    for (int n = 0; n < NN; ++n) { e[n] = expf(logit[n] - m); sum += e[n]; }
     const float inv = 1.f / sum;
-    float* op = w9 + (size_t)b * 9 * HW + (size_t)Y * W + X;
+    float* op = w9 + (size_t)b * NN * HW + (size_t)Y * W + X;
 #pragma unroll
-    for (int n = 0; n < 9; ++n) op[(size_t)n * HW] = e[n] * inv;
+    for (int n = 0; n < NN; ++n) op[(size_t)n * HW] = NB::TIMES_LOGIT ? e[n] * inv * logit[n] : e[n] * inv;
 }
 
 inline int lds_floats(int s) {
@@ -156,11 +183,11 @@ inline int lds_floats(int s) {
 
 extern "C" long long ecm_weights9_scratch_bytes(int B, int h, int w) { return (long long)B * h * w * CF * 4; }
 
-extern "C" int ecm_weights9_fwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2,
-                                const float* W3, float* w9, void* scratch, long long scratch_bytes, int B, int h, int w,
-                                int s, void* stream) {
-    ECM_CHECK_ARG(lr && hr && W0 && W1 && W2 && W3 && w9 && scratch && B > 0 && h > 0 && w > 0 && s > 0);
-    if (s % 2 != 0 || B > 65535) return ECM_EUNSUP;         // the reference exits on odd scale (cmfsm.py:448-449)
+extern "C" int ecm_context_weights_fwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2,
+                                       const float* W3, float* out, void* scratch, long long scratch_bytes, int B, int h,
+                                       int w, int s, int variant, void* stream) {
+    ECM_CHECK_ARG(lr && hr && W0 && W1 && W2 && W3 && out && scratch && B > 0 && h > 0 && w > 0 && s > 0);
+    if (s % 2 != 0 || B > 65535 || variant < 0 || variant > 2) return ECM_EUNSUP;   // the reference exits on odd scale
     if (scratch_bytes < ecm_weights9_scratch_bytes(B, h, w)) return ECM_ESCRATCH;
     hipStream_t st = ecm_stream(stream);
     float* A = static_cast<float*>(scratch);
@@ -168,7 +195,15 @@ extern "C" int ecm_weights9_fwd(const float* lr, const float* hr, const float* W
     hipLaunchKernelGGL(ecm_lr_proj, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, lr, W0, A, B, h * w);
     const int H = h * s, W = w * s;
     dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
-    hipLaunchKernelGGL(ecm_weights9_fwd_kernel, grid, dim3(256), lds_floats(s) * sizeof(float), st, A, hr, W0, W1, W2, W3,
-                       w9, h, w, s);
+    const size_t lds = lds_floats(s) * sizeof(float);
+    if (variant == 0) hipLaunchKernelGGL(ecm_weights_fwd_kernel<0>, grid, dim3(256), lds, st, A, hr, W0, W1, W2, W3, out, h, w, s);
+    else if (variant == 1) hipLaunchKernelGGL(ecm_weights_fwd_kernel<1>, grid, dim3(256), lds, st, A, hr, W0, W1, W2, W3, out, h, w, s);
+    else hipLaunchKernelGGL(ecm_weights_fwd_kernel<2>, grid, dim3(256), lds, st, A, hr, W0, W1, W2, W3, out, h, w, s);
     return ECM_LAUNCH_RESULT();
+}
+
+extern "C" int ecm_weights9_fwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2,
+                                const float* W3, float* w9, void* scratch, long long scratch_bytes, int B, int h, int w,
+                                int s, void* stream) {
+    return ecm_context_weights_fwd(lr, hr, W0, W1, W2, W3, w9, scratch, scratch_bytes, B, h, w, s, 0, stream);
 }

@@ -95,31 +95,55 @@ class BasicBlock(nn.Module):
         return out + x
 
 
-class feature_extraction(nn.Module):
-    """Returns (1/4-res 32-ch feature, 1/2-res layer1 output, full-res 32-ch firstconv output)."""
+# Encoder variants of the registered architectures (all plain PyTorch):
+#   first_tail  "conv": firstconv ends with a bare Conv2d and secondconv starts with GroupNorm+ReLU (cmfsm.py:130-145,
+#               cm_sub_4.py, bilinear_cmf.py);  "convbn": firstconv ends with convbn+ReLU (cmfsm_sub_8.py:131-145 ...)
+#   layers      (stride, dilation) of layer1..4;  pools: AvgPool sizes of branch1..4;  cat_raw: which map joins the
+#   pyramid as "output_raw" (layer2 output, or layer3 output for the /16 nets whose last conv is `lastconv_16`).
+_ENCODERS = {
+    "cmfsm": dict(first_tail="conv", layers=((1, 1), (2, 1), (1, 1), (1, 2)), pools=(64, 32, 16, 8), raw="layer2"),
+    "sub4": dict(first_tail="conv", layers=((1, 1), (2, 1), (1, 2), (1, 4)), pools=(64, 32, 16, 8), raw="layer2"),
+    "sub8": dict(first_tail="convbn", layers=((2, 1), (2, 1), (1, 2), (1, 4)), pools=(4, 32, 16, 8), raw="layer2"),
+    "sub16": dict(first_tail="convbn", layers=((2, 1), (2, 1), (2, 1), (1, 4)), pools=(4, 2, 16, 8), raw="layer3"),
+}
 
-    def __init__(self):
+
+class feature_extraction(nn.Module):
+    """Returns (low-res 32-ch feature, layer1 output, full-res 32-ch firstconv output)  (cmfsm.py:126-236 and the
+    per-architecture copies: cmfsm_sub_8.py:126-236, cmfsm_sub_16.py:127-239, cm_sub_4.py:126-236)."""
+
+    def __init__(self, variant="cmfsm"):
         super().__init__()
+        cfg = _ENCODERS[variant]
+        self.variant = variant
         self.inplanes = 32
-        self.firstconv = nn.Sequential(
-            convbn(3, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
-            convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
-            convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
-            nn.Conv2d(32, 32, kernel_size=3, padding=1, stride=1, bias=False))
-        self.secondconv = nn.Sequential(
-            nn.GroupNorm(NUM_GROUPS, 32), nn.ReLU(inplace=True),
-            convbn(32, 32, 3, 2, 1, 1), nn.ReLU(inplace=True),
-            convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True))
-        self.layer1 = self._make_layer(BasicBlock, 32, 3, 1, 1, 1)
-        self.layer2 = self._make_layer(BasicBlock, 64, 16, 2, 1, 1)
-        self.layer3 = self._make_layer(BasicBlock, 128, 3, 1, 1, 1)
-        self.layer4 = self._make_layer(BasicBlock, 128, 3, 1, 1, 2)
-        for i, pool in enumerate((64, 32, 16, 8), 1):
+        head = [convbn(3, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
+                convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
+                convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True)]
+        if cfg["first_tail"] == "conv":
+            self.firstconv = nn.Sequential(*head, nn.Conv2d(32, 32, kernel_size=3, padding=1, stride=1, bias=False))
+            self.secondconv = nn.Sequential(
+                nn.GroupNorm(NUM_GROUPS, 32), nn.ReLU(inplace=True),
+                convbn(32, 32, 3, 2, 1, 1), nn.ReLU(inplace=True),
+                convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True))
+        else:
+            self.firstconv = nn.Sequential(*head, convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True))
+            self.secondconv = nn.Sequential(
+                convbn(32, 32, 3, 2, 1, 1), nn.ReLU(inplace=True),
+                convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True))
+        (s1, d1), (s2, d2), (s3, d3), (s4, d4) = cfg["layers"]
+        self.layer1 = self._make_layer(BasicBlock, 32, 3, s1, 1, d1)
+        self.layer2 = self._make_layer(BasicBlock, 64, 16, s2, 1, d2)
+        self.layer3 = self._make_layer(BasicBlock, 128, 3, s3, 1, d3)
+        self.layer4 = self._make_layer(BasicBlock, 128, 3, s4, 1, d4)
+        for i, pool in enumerate(cfg["pools"], 1):
             setattr(self, f"branch{i}", nn.Sequential(
                 nn.AvgPool2d((pool, pool), stride=(pool, pool)), convbn(128, 32, 1, 1, 0, 1), nn.ReLU(inplace=True)))
-        self.lastconv = nn.Sequential(
-            convbn(320, 128, 3, 1, 1, 1), nn.ReLU(inplace=True),
+        last = nn.Sequential(
+            convbn(320 if cfg["raw"] == "layer2" else 384, 128, 3, 1, 1, 1), nn.ReLU(inplace=True),
             nn.Conv2d(128, 32, kernel_size=1, padding=0, stride=1, bias=False))
+        setattr(self, "lastconv" if cfg["raw"] == "layer2" else "lastconv_16", last)
+        self._raw_is_layer3 = cfg["raw"] == "layer3"
 
     def _make_layer(self, block, planes, blocks, stride, pad, dilation):
         downsample = None
@@ -136,11 +160,16 @@ class feature_extraction(nn.Module):
         output_all = self.firstconv(x)
         output_rt = self.layer1(self.secondconv(output_all))
         output_raw = self.layer2(output_rt)
-        output_skip = self.layer4(self.layer3(output_raw))
+        if self._raw_is_layer3:                       # cmfsm_sub_16.py:205-207
+            output_raw = self.layer3(output_raw)
+            output_skip = self.layer4(output_raw)
+        else:
+            output_skip = self.layer4(self.layer3(output_raw))
         size = output_skip.shape[-2:]
         pyramid = [F.interpolate(getattr(self, f"branch{i}")(output_skip), size, mode="bilinear", align_corners=False)
                    for i in (4, 3, 2, 1)]
-        feature = self.lastconv(torch.cat([output_raw, output_skip] + pyramid, 1))
+        last = self.lastconv_16 if self._raw_is_layer3 else self.lastconv
+        feature = last(torch.cat([output_raw, output_skip] + pyramid, 1))
         return feature, output_rt, output_all
 
 
@@ -287,7 +316,150 @@ class cmfsm(nn.Module):
         return self.hot_path(lr_l, hr_l, lr_r)
 
 
-_MODELS = {"cmfsm": cmfsm}
+class similarity_measure2(nn.Module):
+    """3->3->2->1 1x1-conv MLP on the offset table (cm_sub_4.py: instantiated, never used in forward)."""
+
+    def __init__(self):
+        super().__init__()
+        self.inplanes = 32
+        self.conv0 = nn.Conv2d(3, 3, kernel_size=1, bias=False)
+        self.relu0 = nn.LeakyReLU(inplace=True)
+        self.conv1 = nn.Conv2d(3, 2, kernel_size=1, bias=False)
+        self.relu1 = nn.LeakyReLU(inplace=True)
+        self.conv2 = nn.Conv2d(2, 1, kernel_size=1, bias=False)
+        self.relu2 = nn.LeakyReLU(inplace=True)
+
+    def forward(self, x):
+        return self.relu2(self.conv2(self.relu1(self.conv1(self.relu0(self.conv0(x))))))
+
+
+class six_related_context_mapping(nn.Module):
+    """cmfsm_sub_8.py:440-572 (same text in cmfsm_sub_16.py and cm_sub_4/8/16.py):
+    forward(lr, hr, lr_r, hr_r) -> ((mapping, mapping_r, mapping_l, mapping_t, mapping_b),
+                                    (mapping_target, mapping_target_r, mapping_target_l)), each [B,1,H,W]."""
+
+    def __init__(self, with_similarity2=False):
+        super().__init__()
+        self.similarity1 = similarity_measure1()
+        self.similarity1.relu3 = nn.LeakyReLU(inplace=True)          # cmfsm_sub_8.py:318 (no parameters)
+        if with_similarity2:
+            self.similarity2 = similarity_measure2()                 # cm_sub_4.py only; unused in forward
+        self.fuse = nn.Sequential(nn.Conv2d(2, 1, kernel_size=1, bias=False), nn.LeakyReLU(inplace=True))   # unused
+
+    def planes(self, lr_feature, hr_feature, lr_feature_r, hr_feature_r):
+        m = self.similarity1
+        ws = (m.conv0.weight, m.conv1.weight, m.conv2.weight, m.conv3.weight)
+        return (ops.context_weights(lr_feature, hr_feature, *ws, 1), ops.context_weights(lr_feature_r, hr_feature_r, *ws, 2))
+
+    def forward(self, lr_feature, hr_feature, lr_feature_r, hr_feature_r):
+        m5, mt3 = self.planes(lr_feature, hr_feature, lr_feature_r, hr_feature_r)
+        return tuple(m5[:, n:n + 1] for n in range(5)), tuple(mt3[:, n:n + 1] for n in range(3))
+
+
+class _ECMNet(nn.Module):
+    """Shared skeleton of the registered architectures: encoder -> cost volume -> dres0/1 -> 1 or 3 hourglasses ->
+    classifiers -> head.  Subclasses set ENCODER, HOURGLASSES, HEAD, ACCUMULATE exactly as their reference file does."""
+    ENCODER, HOURGLASSES, HEAD, ACCUMULATE, SIM2 = "cmfsm", 3, "eight", True, False
+
+    def __init__(self, maxdisp=192):
+        super().__init__()
+        self.maxdisp = maxdisp
+        self.feature_extraction = feature_extraction(self.ENCODER)
+        self.dres0 = nn.Sequential(convbn_3d(64, 32, 3, 1, 1), HipReLU(inplace=True),
+                                   convbn_3d(32, 32, 3, 1, 1), HipReLU(inplace=True))
+        self.dres1 = nn.Sequential(convbn_3d(32, 32, 3, 1, 1), HipReLU(inplace=True),
+                                   convbn_3d(32, 32, 3, 1, 1))
+        for i in range(self.HOURGLASSES):
+            setattr(self, f"dres{i + 2}", hourglass(32))
+        for i in range(self.HOURGLASSES):
+            setattr(self, f"classif{i + 1}", nn.Sequential(
+                convbn_3d(32, 32, 3, 1, 1), HipReLU(inplace=True),
+                HipConv3d(32, 1, kernel_size=3, padding=1, stride=1, bias=False)))
+        if self.HEAD in ("five", "volume"):
+            self.mapping_matrix = six_related_context_mapping(self.SIM2)
+        for m in self.modules():                                      # PSMNet init rule, e.g. cmfsm_sub_8.py:703-711
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(0, math.sqrt(2.0 / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
+            elif isinstance(m, nn.Conv3d):
+                k = m.kernel_size
+                m.weight.data.normal_(0, math.sqrt(2.0 / (k[0] * k[1] * k[2] * m.out_channels)))
+
+    def hot_path(self, lr_l, hr_l, lr_r, hr_r, out_hw=None):
+        scale = hr_l.shape[-1] // lr_l.shape[-1]
+        planes = None
+        if self.HEAD in ("five", "volume"):
+            planes = self.mapping_matrix.planes(lr_l, hr_l, lr_r, hr_r)
+        cost = ops.cost_volume(lr_l, lr_r, self.maxdisp // scale)
+        cost0 = _cbn(self.dres0[0], cost, relu=True)
+        cost0 = _cbn(self.dres0[2], cost0, relu=True)
+        cost0 = _cbn(self.dres1[2], _cbn(self.dres1[0], cost0, relu=True), skip=cost0)
+        heads, x, pre1, post = [], cost0, None, None
+        for i in range(self.HOURGLASSES):
+            out, pre, post = getattr(self, f"dres{i + 2}")(x, pre1 if i > 0 else None, post, residual=cost0)
+            if i == 0:
+                pre1 = pre
+            x = out
+            clf = getattr(self, f"classif{i + 1}")
+            heads.append(clf[2](_cbn(clf[0], out, relu=True)).squeeze(1))
+        c = torch.stack(heads, 0)                                        # raw classifier outputs [NH,B,Dl,h,w]
+        if self.HEAD == "five":                                          # cmfsm_sub_8.py:757-803 (heads NOT accumulated)
+            disp = torch.cat([ops.softargmin_heads(c[k:k + 1]) for k in range(c.shape[0])], 0)
+            m5 = planes[0]
+            w9 = torch.cat([m5[:, 0:1], m5[:, 2:3], m5[:, 1:2], m5[:, 3:5], torch.zeros_like(m5[:, :4])], 1)
+            preds = ops.ecm_aggregate9(disp, w9, scale)                  # planes reordered c,l,r,t,b + 4 zero diagonals
+            return tuple(preds[k].unsqueeze(1) for k in range(3))
+        if self.HEAD == "volume":                                        # cmfsm_sub_16.py:767-848 / cm_sub_8.py:765-800
+            preds = ops.volume_mapping(c, planes[0], planes[1], scale)
+        else:                                                            # bilinear_cmf.py:447-471
+            H, W = out_hw if out_hw is not None else hr_l.shape[-2:]
+            preds = ops.trilinear_softargmin(c, self.maxdisp, H, W)
+        preds = [preds[k] for k in range(preds.shape[0])]
+        while len(preds) < 3:                                            # cm_sub_*: `return pred1, pred1, pred1`
+            preds.append(preds[0])
+        return tuple(preds)
+
+    def forward(self, left, right):
+        lr_l, _, hr_l = self.feature_extraction(left)
+        lr_r, _, hr_r = self.feature_extraction(right)
+        return self.hot_path(lr_l, hr_l, lr_r, hr_r, out_hw=left.shape[-2:])
+
+
+class cmfsm_sub_8(_ECMNet):
+    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub8", 3, "five", False
+
+
+class cmfsm_sub_16(_ECMNet):
+    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub16", 3, "volume", True
+
+
+class cm_sub_4(_ECMNet):
+    ENCODER, HOURGLASSES, HEAD, ACCUMULATE, SIM2 = "sub4", 1, "volume", False, True
+
+
+class cm_sub_8(_ECMNet):
+    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub8", 1, "volume", False
+
+
+class cm_sub_16(_ECMNet):
+    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub16", 1, "volume", False
+
+
+class bilinear_cmf(_ECMNet):
+    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub4", 3, "trilinear", True
+
+
+class bilinear_cmf_sub_8(_ECMNet):
+    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub8", 3, "trilinear", True
+
+
+class bilinear_cmf_sub_16(_ECMNet):
+    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub16", 3, "trilinear", True
+
+
+_MODELS = {"cmfsm": cmfsm, "cmfsm_sub_8": cmfsm_sub_8, "cmfsm_sub_16": cmfsm_sub_16, "cm_sub_4": cm_sub_4,
+           "cm_sub_8": cm_sub_8, "cm_sub_16": cm_sub_16, "bilinear_cmf": bilinear_cmf,
+           "bilinear_cmf_sub_8": bilinear_cmf_sub_8, "bilinear_cmf_sub_16": bilinear_cmf_sub_16}
+
 
 
 def get_model(name):

@@ -190,6 +190,87 @@ def ecm_weights9(lr, hr, W0, W1, W2, W3):
     return ECMWeights9.apply(lr, hr, W0, W1, W2, W3)
 
 
+_VARIANT_PLANES = {0: 9, 1: 5, 2: 3}
+
+
+class ContextWeights(torch.autograd.Function):
+    """General context-mapping weights: variant 0 eight_related (cmfsm.py:431-593), 1/2 six_related on the reference /
+    target image (cmfsm_sub_8.py:440-572).  lr [B,32,h,w], hr [B,32,H,W] -> [B,N,H,W]."""
+
+    @staticmethod
+    def forward(ctx, lr, hr, W0, W1, W2, W3, variant):
+        _chk(lr, hr, W0, W1, W2, W3)
+        lr, hr = _c(lr), _c(hr)
+        W0, W1, W2, W3 = (_c(t) for t in (W0, W1, W2, W3))
+        B, Cc, h, w = lr.shape
+        H, W = hr.shape[-2:]
+        s = W // w
+        if s % 2 != 0:
+            raise ValueError("odd scale between hr and lr features (the reference calls exit() here)")
+        if Cc != 32 or hr.shape[1] != 32 or H != h * s or W != w * s:
+            raise RuntimeError(f"context_weights: unsupported shapes lr {tuple(lr.shape)} hr {tuple(hr.shape)}")
+        out = torch.empty(B, _VARIANT_PLANES[variant], H, W, device=lr.device, dtype=lr.dtype)
+        nb = _lib.query("ecm_weights9_scratch_bytes", B, h, w)
+        scratch = _scratch(nb, lr.device)
+        _lib.call("ecm_context_weights_fwd", _p(lr), _p(hr), _p(W0), _p(W1), _p(W2), _p(W3), _p(out), _p(scratch),
+                  C.c_longlong(nb), B, h, w, s, variant, _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("six_related context weights: backward kernel not built yet (forward/inference only)")
+
+
+def context_weights(lr, hr, W0, W1, W2, W3, variant):
+    if variant == 0:
+        return ECMWeights9.apply(lr, hr, W0, W1, W2, W3)
+    return ContextWeights.apply(lr, hr, W0, W1, W2, W3, int(variant))
+
+
+class VolumeMapping(torch.autograd.Function):
+    """Fused volume-mapping head (cmfsm_sub_16.py:767-801): c [NH,B,Dl,h,w], m5 [B,5,H,W], mt3 [B,3,H,W] -> [NH,B,H,W]."""
+
+    @staticmethod
+    def forward(ctx, c, m5, mt3, scale):
+        _chk(c, m5, mt3)
+        c, m5, mt3 = _c(c), _c(m5), _c(mt3)
+        NH, B, Dl, h, w = c.shape
+        out = torch.empty(NH, B, h * scale, w * scale, device=c.device, dtype=c.dtype)
+        _lib.call("ecm_volume_mapping_fwd", _p(c), C.c_longlong(B * Dl * h * w), _p(m5), _p(mt3), _p(out), NH, B, Dl, h, w,
+                  scale, _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("volume-mapping head: backward kernel not built yet (forward/inference only)")
+
+
+def volume_mapping(c, m5, mt3, scale):
+    return VolumeMapping.apply(c, m5, mt3, int(scale))
+
+
+class TrilinearSoftArgmin(torch.autograd.Function):
+    """Fused trilinear head (bilinear_cmf.py:447-471): c [NH,B,Dl,h,w] -> [NH,B,H,W]."""
+
+    @staticmethod
+    def forward(ctx, c, Do, H, W):
+        _chk(c)
+        c = _c(c)
+        NH, B, Dl, h, w = c.shape
+        out = torch.empty(NH, B, H, W, device=c.device, dtype=c.dtype)
+        _lib.call("ecm_trilinear_softargmin_fwd", _p(c), C.c_longlong(B * Dl * h * w), _p(out), NH, B, Dl, h, w, Do, H, W,
+                  _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("trilinear head: backward kernel not built yet (forward/inference only)")
+
+
+def trilinear_softargmin(c, Do, H, W):
+    return TrilinearSoftArgmin.apply(c, int(Do), int(H), int(W))
+
+
 # ------------------------------------------------------------------------------------ a5-a7 conv / deconv / GN
 def _pack_conv(w, flip_transpose=False):
     Co, Ci = w.shape[0], w.shape[1]

@@ -75,6 +75,26 @@ int ecm_weights9_bwd(const float* lr, const float* hr, const float* W0, const fl
                      float* glr, float* ghr, float* gW, void* scratch, long long scratch_bytes,
                      int B, int h, int w, int s, void* stream);
 
+/* ---- a4: six-related context mapping (cmfsm_sub_8.py:440-572; same text in cmfsm_sub_16.py, cm_sub_4/8/16.py) and the
+ * general form of a3.  variant 0: eight_related (9 planes, softmax; == ecm_weights9_fwd); variant 1: six_related on the
+ * reference image (5 planes c,r,l,t,b; zero padding; extra LeakyReLU; output softmax*logit); variant 2: six_related on
+ * the target image (3 planes c,r,l).  out: [B,N,H,W], N = 9/5/3.  Any even scale s. */
+int ecm_context_weights_fwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2,
+                            const float* W3, float* out, void* scratch, long long scratch_bytes,
+                            int B, int h, int w, int s, int variant, void* stream);
+
+/* ---- a10: volume mapping head (cmfsm_sub_16.py:767-801 [+804-848], cm_sub_8.py:765-800), fused: NN-upsample of the LR
+ * logits in D,H,W, 5-neighbour spatial fuse with m5 [B,5,H,W] (c,r,l,t,b), three target-weight volumes built from
+ * mt3 [B,3,H,W] (c,r,l) shifted by the disparity, +-s fuse along D, softmax over D = Dl*s, regression.
+ * c: raw classifier outputs [nheads][B,Dl,h,w] (head k uses c_0+...+c_k); disp: [nheads,B,H,W]. */
+int ecm_volume_mapping_fwd(const float* c0, long long head_stride, const float* m5, const float* mt3, float* disp,
+                           int nheads, int B, int Dl, int h, int w, int s, void* stream);
+
+/* ---- a11: trilinear head (bilinear_cmf.py:447-471), fused: F.interpolate(trilinear, align_corners=False) of the LR
+ * logits to [Do,H,W], softmax over Do, regression.  c as above (cumulative over heads); disp: [nheads,B,H,W]. */
+int ecm_trilinear_softargmin_fwd(const float* c0, long long head_stride, float* disp,
+                                 int nheads, int B, int Dl, int h, int w, int Do, int H, int W, void* stream);
+
 /* ---- a5-a7: 3-D aggregation (cmfsm.py:49-58 convbn_3d, 240-303 hourglass, 604-634) ----------
  * Weights are taken in the reference (checkpoint) layouts and repacked on device by the *_pack calls. */
 

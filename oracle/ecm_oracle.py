@@ -292,3 +292,129 @@ def train_loss(preds, gt, maxdisp=192):
     return (0.5 * F.smooth_l1_loss(o1[mask], gt[mask], reduction="mean")
             + 0.7 * F.smooth_l1_loss(o2[mask], gt[mask], reduction="mean")
             + F.smooth_l1_loss(o3[mask], gt[mask], reduction="mean"))
+
+
+# ============================================================================
+# The other registered architectures
+# ============================================================================
+# six_related_context_mapping (cmfsm_sub_8.py:440-572; identical text in cmfsm_sub_16.py, cm_sub_4/8/16.py):
+# reference-image planes in return order [c, r, l, t, b] (cmfsm_sub_8.py:566), right uses table 1 and left table 2
+# (:503,525); target-image planes [c, r, l] (:568); zero padding (:461-462); output softmax*logit (:572).
+SIX_LEFT = ((0, 0, 0), (0, 1, 1), (0, -1, 2), (-1, 0, 3), (1, 0, 4))
+SIX_RIGHT = ((0, 0, 0), (0, 1, 1), (0, -1, 2))
+
+
+def _six_planes(lr, hr, sd, key, neighbours):
+    B, C, H, W = hr.shape
+    s = W // lr.shape[-1]
+    tabs = [t.repeat(B, 1, H // s, W // s) for t in offset_tables(s)]        # generic even scale (:455-470)
+    lr_up = nn_upsample(lr, s)
+    logits = []
+    for dy, dx, t in neighbours:
+        ry, rx, sy, sx = _slices(dy, dx, s, H, W)
+        rep = torch.cat([lr_up[:, :, sy, sx], hr[:, :, ry, rx], tabs[t][:, :, sy, sx]], 1)
+        val = similarity_mlp(rep, sd, key, final_act=True)                    # relu3, cmfsm_sub_8.py:318,342
+        full = torch.zeros(B, 1, H, W, dtype=hr.dtype)                         # zero padding participates in the softmax
+        full[:, :, ry, rx] = val
+        logits.append(full)
+    allp = torch.cat(logits, 1)
+    return F.softmax(allp, dim=1) * allp
+
+
+def ecm_weights_six(lr, hr, lr_r, hr_r, sd, key="mapping_matrix.similarity1"):
+    """-> (m5 [B,5,H,W] for the reference image, mt3 [B,3,H,W] for the target image)."""
+    return _six_planes(lr, hr, sd, key, SIX_LEFT), _six_planes(lr_r, hr_r, sd, key, SIX_RIGHT)
+
+
+def ecm_aggregate_five(d_lr, m5, scale):
+    """cmfsm_sub_8.py:763-772: d_lr [B,h,w], m5 [B,5,H,W] (c,r,l,t,b) -> [B,1,H,W]."""
+    s = scale
+    pred = (s * nn_upsample(d_lr, s)).unsqueeze(1)
+    H, W = pred.shape[-2:]
+    out = pred * m5[:, 0:1]
+    for n, (dy, dx, _) in enumerate(SIX_LEFT):
+        if n == 0:
+            continue
+        ry, rx, sy, sx = _slices(dy, dx, s, H, W)
+        out[:, :, ry, rx] = out[:, :, ry, rx] + pred[:, :, sy, sx] * m5[:, n:n + 1, ry, rx]
+    return out
+
+
+def volume_mapping(cost_lr, m5, mt3, scale, maxdisp=192):
+    """cmfsm_sub_16.py:767-801 (same in cm_sub_*): cost_lr [B,Dl,h,w] (already accumulated over heads),
+    m5 [B,5,H,W], mt3 [B,3,H,W] -> disparity [B,H,W].  Follows the reference op sequence incl. the python loop."""
+    s = scale
+    cost = nn_upsample(cost_lr, s).repeat_interleave(s, 1)                       # :768-773  [B,maxdisp,H,W]
+    H, W = cost.shape[-2:]
+    fused = cost * m5[:, 0:1]
+    for n, (dy, dx, _) in enumerate(SIX_LEFT):                                    # :774-778
+        if n == 0:
+            continue
+        ry, rx, sy, sx = _slices(dy, dx, s, H, W)
+        fused[:, :, ry, rx] = fused[:, :, ry, rx] + cost[:, :, sy, sx] * m5[:, n:n + 1, ry, rx]
+    vols = [torch.ones_like(cost) for _ in range(3)]                              # :782-784
+    for d in range(maxdisp):                                                      # :785-794
+        for v, plane in zip(vols, (mt3[:, 0], mt3[:, 1], mt3[:, 2])):
+            if d == 0:
+                v[:, 0] = plane
+            elif d < W:
+                v[:, d, :, d:] = plane[:, :, :-d]
+    t0, tr, tl = vols
+    out = fused * t0                                                              # :796
+    out[:, :-s] = out[:, :-s] + fused[:, s:] * tl[:, :-s]                         # :797
+    out[:, s:] = out[:, s:] + fused[:, :-s] * tr[:, s:]                           # :798
+    return soft_argmin(out)                                                       # :800-801
+
+
+def trilinear_head(cost_lr, maxdisp, H, W):
+    """bilinear_cmf.py:447-471: cost_lr [B,Dl,h,w] -> disparity [B,H,W]."""
+    up = F.interpolate(cost_lr.unsqueeze(1), [maxdisp, H, W], mode="trilinear", align_corners=False).squeeze(1)
+    return soft_argmin(up)
+
+
+ARCH_SPEC = {  # name: (head kind, hourglasses, accumulate logits across heads)
+    "cmfsm": ("eight", 3, True), "cmfsm_sub_8": ("five", 3, False), "cmfsm_sub_16": ("volume", 3, True),
+    "cm_sub_4": ("volume", 1, False), "cm_sub_8": ("volume", 1, False), "cm_sub_16": ("volume", 1, False),
+    "bilinear_cmf": ("trilinear", 3, True), "bilinear_cmf_sub_8": ("trilinear", 3, True),
+    "bilinear_cmf_sub_16": ("trilinear", 3, True),
+}
+
+
+def hot_path_arch(arch, lr_l, hr_l, lr_r, hr_r, sd, maxdisp=192):
+    """Post-encoder path of any registered architecture -> 3 predictions (cm_sub_* repeat pred1, cm_sub_4.py:784)."""
+    kind, nhg, accumulate = ARCH_SPEC[arch]
+    s = hr_l.shape[-1] // lr_l.shape[-1]
+    cost = cost_volume(lr_l, lr_r, maxdisp // s)
+    cost0 = dres0(cost, sd)
+    cost0 = dres1(cost0, sd) + cost0
+    outs, pre1, post = [], None, None
+    x = cost0
+    for i in range(nhg):
+        key = f"dres{i + 2}"
+        out, pre, post_new = hourglass(x, pre1 if i > 0 else None, post, sd, key)
+        if i == 0:
+            pre1 = pre
+        post = post_new
+        x = out + cost0
+        outs.append(x)
+    logits = []
+    for i, o in enumerate(outs):
+        c = classif(o, sd, f"classif{i + 1}").squeeze(1)
+        if accumulate and logits:
+            c = c + logits[-1]
+        logits.append(c)
+    if kind == "eight":
+        w9 = ecm_weights_eight(lr_l, hr_l, sd)
+        preds = [ecm_aggregate_eight(soft_argmin(c), w9, s) for c in logits]
+    elif kind == "five":
+        m5, _ = ecm_weights_six(lr_l, hr_l, lr_r, hr_r, sd)
+        preds = [ecm_aggregate_five(soft_argmin(c), m5, s) for c in logits]
+    elif kind == "volume":
+        m5, mt3 = ecm_weights_six(lr_l, hr_l, lr_r, hr_r, sd)
+        preds = [volume_mapping(c, m5, mt3, s, maxdisp) for c in logits]
+    else:
+        H, W = hr_l.shape[-2:]
+        preds = [trilinear_head(c, maxdisp, H, W) for c in logits]
+    while len(preds) < 3:
+        preds.append(preds[0])
+    return tuple(preds)

@@ -353,3 +353,67 @@ def test_full_model_golden(ecm, cmfsm_sd):
 def test_cpu_tensor_is_refused(ecm):
     with pytest.raises(RuntimeError):
         ecm.ops.cost_volume(torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 4), 2)
+
+
+# ------------------------------------------------------------------ the other registered architectures (a4, a10, a11)
+from test_oracle_golden import ARCHS, arch_inputs, arch_sd  # noqa: E402
+
+
+@pytest.mark.parametrize("B,h,w,s", [(1, 4, 8, 8), (2, 3, 5, 4), (1, 2, 4, 16), (1, 5, 9, 8)])
+def test_six_related_weights_vs_oracle(ecm, cmfsm_sd, B, h, w, s):
+    lr, hr = seeded("sx.lr", B, 32, h, w), seeded("sx.hr", B, 32, h * s, w * s)
+    lr_r, hr_r = seeded("sx.lr_r", B, 32, h, w), seeded("sx.hr_r", B, 32, h * s, w * s)
+    Ws = [dev(t) for t in _mlp(cmfsm_sd)]
+    m5 = ecm.ops.context_weights(dev(lr), dev(hr), *Ws, 1)
+    mt3 = ecm.ops.context_weights(dev(lr_r), dev(hr_r), *Ws, 2)
+    rm5, rmt3 = O.ecm_weights_six(lr, hr, lr_r, hr_r, cmfsm_sd)
+    close(m5, rm5, 1e-4, 1e-5)
+    close(mt3, rmt3, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("NH,B,Dl,h,w,s", [(1, 1, 12, 4, 4, 16), (3, 1, 12, 3, 5, 16), (1, 2, 24, 4, 8, 8), (2, 1, 48, 4, 8, 4)])
+def test_volume_mapping_vs_oracle(ecm, NH, B, Dl, h, w, s):
+    c = seeded("vm.c", NH, B, Dl, h, w, scale=1.5)
+    m5 = seeded("vm.m5", B, 5, h * s, w * s, scale=0.5)
+    mt3 = seeded("vm.mt3", B, 3, h * s, w * s, scale=0.5)
+    out = ecm.ops.volume_mapping(dev(c), dev(m5), dev(mt3), s)
+    ref = torch.stack([O.volume_mapping(c[:k + 1].sum(0), m5, mt3, s, Dl * s) for k in range(NH)], 0)
+    close(out, ref, 1e-4, 2e-4)
+
+
+@pytest.mark.parametrize("NH,B,Dl,h,w,Do,H,W", [(1, 1, 48, 4, 8, 192, 16, 32), (3, 2, 12, 3, 5, 192, 48, 80),
+                                               (2, 1, 24, 4, 6, 192, 30, 50)])
+def test_trilinear_head_vs_oracle(ecm, NH, B, Dl, h, w, Do, H, W):
+    c = seeded("tl.c", NH, B, Dl, h, w, scale=1.5)
+    out = ecm.ops.trilinear_softargmin(dev(c), Do, H, W)
+    ref = torch.stack([O.trilinear_head(c[:k + 1].sum(0), Do, H, W) for k in range(NH)], 0)
+    close(out, ref, 1e-4, 2e-4)
+
+
+@pytest.mark.parametrize("arch", list(ARCHS))
+def test_arch_hot_path_golden(ecm, arch):
+    """Every registered architecture's post-encoder path on the HIP kernels vs the reference's own forward (fixture)."""
+    g = load_golden(f"arch_{arch}")
+    sd = arch_sd(arch)
+    model = ecm.get_model(arch)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("feature_extraction") for k in missing)
+    model = model.cuda()
+    lr_l, hr_l, lr_r, hr_r = (dev(t) for t in arch_inputs(arch))
+    with torch.no_grad():
+        preds = model.hot_path(lr_l, hr_l, lr_r, hr_r)
+    for i, p in enumerate(preds, 1):
+        assert p.shape == g[f"pred{i}"].shape, (arch, p.shape, g[f"pred{i}"].shape)
+        d = (p.cpu() - g[f"pred{i}"]).abs()
+        assert d.max() <= 2e-2 and d.mean() <= 1e-3, (arch, i, d.max(), d.mean())
+
+
+def test_arch_state_dict_contracts(ecm):
+    import json, os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "arch_state_shapes.json")) as f:
+        shapes = json.load(f)
+    for arch, sh in shapes.items():
+        sd = ecm.get_model(arch).state_dict()
+        assert list(sd.keys()) == list(sh.keys()), arch
+        assert all(list(sd[k].shape) == sh[k] for k in sh), arch

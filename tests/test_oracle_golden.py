@@ -132,3 +132,51 @@ def test_g8_full_model(cmfsm_sd):
             d = (o[i][..., ::4, ::4] - g[name]).abs()
             assert d.max() <= 2e-2 and d.mean() <= 1e-3, (name, d.max(), d.mean())
         close(O.train_loss(o, gt), g["loss"], 1e-4, 1e-4)
+
+
+ARCHS = {"cmfsm_sub_8": (8, 4, 8), "cmfsm_sub_16": (16, 4, 4), "cm_sub_4": (4, 4, 8), "cm_sub_8": (8, 4, 8),
+         "cm_sub_16": (16, 4, 4), "bilinear_cmf": (4, 4, 8), "bilinear_cmf_sub_8": (8, 4, 8),
+         "bilinear_cmf_sub_16": (16, 4, 4)}
+
+
+def arch_inputs(arch):
+    s, h, w = ARCHS[arch]
+    return (seeded(f"{arch}.lr_l", 1, 32, h, w), seeded(f"{arch}.hr_l", 1, 32, s * h, s * w),
+            seeded(f"{arch}.lr_r", 1, 32, h, w), seeded(f"{arch}.hr_r", 1, 32, s * h, s * w))
+
+
+def arch_sd(arch):
+    import json, os
+    from conftest import GOLDEN
+    from oracle.weights import make_state_dict
+    with open(os.path.join(GOLDEN, "arch_state_shapes.json")) as f:
+        shapes = json.load(f)[arch]
+    return make_state_dict({k: v for k, v in shapes.items() if not k.startswith("feature_extraction")})
+
+
+import pytest
+
+
+@pytest.mark.parametrize("arch", list(ARCHS))
+def test_arch_hot_path_oracle_vs_reference(arch):
+    """Rows a4/a10/a11: the oracle's restatement of each architecture's post-encoder path against the reference's own
+    forward() (stub encoder) -- outputs, mapping planes and input gradients."""
+    g = load_golden(f"arch_{arch}")
+    sd = arch_sd(arch)
+    lr_l, hr_l, lr_r, hr_r = (t.requires_grad_() for t in arch_inputs(arch))
+    if "m5" in g:
+        m5, mt3 = O.ecm_weights_six(lr_l, hr_l, lr_r, hr_r, sd)
+        close(m5.detach(), g["m5"], 1e-4, 1e-6)
+        close(mt3.detach(), g["mt3"], 1e-4, 1e-6)
+    preds = O.hot_path_arch(arch, lr_l, hr_l, lr_r, hr_r, sd)
+    for i, p in enumerate(preds, 1):
+        assert p.shape == g[f"pred{i}"].shape
+        d = (p.detach() - g[f"pred{i}"]).abs()
+        assert d.max() <= 2e-2 and d.mean() <= 1e-3, (arch, i, d.max(), d.mean())
+    loss = sum((p * seeded(f"{arch}.G{i}", *p.shape)).sum() for i, p in enumerate(preds))
+    loss.backward()
+    for nm, t in (("g_lr_l", lr_l), ("g_hr_l", hr_l), ("g_lr_r", lr_r), ("g_hr_r", hr_r)):
+        if nm in g:
+            ref = g[nm]
+            tol = 2e-2 * float(ref.abs().max()) + 1e-6
+            assert (t.grad - ref).abs().max() <= tol, (arch, nm, (t.grad - ref).abs().max(), tol)

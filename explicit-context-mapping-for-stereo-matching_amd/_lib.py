@@ -27,6 +27,8 @@ PROTOTYPES = {
     "ecm_weights9_scratch_bytes": (_LL, [_I, _I, _I]),
     "ecm_weights9_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
     "ecm_context_weights_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
+    "ecm_context_weights_bwd_scratch_bytes": (_LL, [_I, _I, _I, _I, _I]),
+    "ecm_context_weights_bwd": (_I, [_P] * 11 + [_P, _LL, _I, _I, _I, _I, _I, _P]),
     "ecm_volume_mapping_fwd": (_I, [_P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_trilinear_softargmin_fwd": (_I, [_P, _LL, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_weights9_bwd_scratch_bytes": (_LL, [_I, _I, _I, _I]),

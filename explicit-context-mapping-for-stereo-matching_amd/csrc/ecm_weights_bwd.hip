@@ -1,35 +1,31 @@
-// Backward of the eight-related ECM weights (autograd of eight_related_context_mapping.forward,
-// cmfsm.py:443-593): gradients w.r.t. lr, hr and the 2,760 MLP weights from gw9 [B,9,H,W].
+// Backward of the context-mapping weight generators (autograd of eight_related_context_mapping.forward,
+// cmfsm.py:443-593, and of six_related_context_mapping.forward, cmfsm_sub_8.py:449-572): gradients w.r.t. lr, hr and
+// the 2,760 MLP weights from the gradient of the [B,N,H,W] planes.  Variants as in ecm_nbr.h; scale s in {4, 8, 16, ...}
+// (s % 4 == 0).
 //
-// Kernel B (per HR pixel, one wave per 64 consecutive X of one row, workgroup = 4 rows = one LR cell row):
-//   softmax backward -> g_logit[n]; per in-image neighbour recompute the MLP and back-propagate to g0 = dL/d(h0pre).
-//   * ghr        = W0_hr^T sum_n g0                       (per pixel, registers)
-//   * gA9[cell,n] = sum over the cell's 16 pixels of g0   (per source cell and neighbour; plain stores, no atomics)
+// Kernel B (per HR pixel, one wave per 64 consecutive X of one row, workgroup = 4 rows inside one LR cell row):
+//   softmax (or softmax*logit) backward -> g_logit[n]; per in-image neighbour recompute the MLP and back-propagate
+//   to g0 = dL/d(h0pre).
+//   * ghr         = W0_hr^T sum_n g0                        (per pixel, registers)
+//   * gA9[rb,cell,n] = sum over the cell's pixels in this 4-row block of g0   (plain stores, no atomics)
 //   * weight gradients are sums over PIXELS of per-pixel outer products, i.e. GEMMs whose reduction index is
 //     the lane: each wave transposes the operands through a [64 px][48] LDS scratch and reduces them on the
 //     fp32 matrix cores (v_mfma_f32_16x16x4_f32, K = 4 pixels per step); accumulators persist across tiles.
-// Kernel C (per LR cell): gA = sum_n gA9[cell - d_n, n];  glr = W0_lr^T gA;  gW0_lr partials.
+// Kernel C (per LR cell): gA = sum_n sum_rowblocks gA9[.., cell - d_n, n];  glr = W0_lr^T gA;  gW0_lr partials.
 // Kernel D: fixed-order sum of the per-workgroup partials -> gW (deterministic).
-// Scale 4 only (cmfsm); other scales return ECM_EUNSUP.
 #include "common.h"
+#include "ecm_nbr.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CF = 32, S = 4, TX = 64, TY = 4;
+constexpr int CF = 32, TX = 64, TY = 4;
 constexpr int ASTRIDE = 36;
-constexpr int NCX = TX / S + 2, NCY = 3;              // cell window of a tile (+1 halo)
+constexpr int NCXMAX = TX / 4 + 2, NCY = 3;           // cell window of a tile (+1 halo), sized for the smallest scale
 constexpr int UST = 48;                               // per-pixel stride of the transpose scratch (== 16 mod 32)
 constexpr int PB_HR = 0, PB_OFF = 1024, PB_W1 = 1088, PB_W2 = 1600, PB_W3 = 1728, PB_N = 1736;   // partial layout
 
-__constant__ int bDy9[9] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
-__constant__ int bDx9[9] = {0, -1, 1, 0, 0, -1, 1, -1, 1};
-__constant__ int bTab9[9] = {0, 1, 2, 3, 4, 1, 2, 3, 4};
-
-__device__ __forceinline__ float cpat(int r) { return (float)(r < S / 2 ? r - S / 2 : r - S / 2 + 1); }
-__device__ __forceinline__ float offx(int t, int r) { return t == 1 ? (float)(S - r) : t == 2 ? (float)(r + 1) : cpat(r); }
-__device__ __forceinline__ float offy(int t, int r) { return t == 3 ? (float)(S - r) : t == 4 ? (float)(r + 1) : cpat(r); }
 __device__ __forceinline__ float dleaky(float h) { return h > 0.f ? 1.f : 0.01f; }      // phi'(pre); sign(h)==sign(pre)
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -63,19 +59,57 @@ __global__ __launch_bounds__(256) void bwd_lr_proj(const float* __restrict__ lr,
     }
 }
 
-__global__ __launch_bounds__(256, 1) void ecm_weights9_bwd_kernel(
+// forward MLP of one neighbour: a = projected LR cell (LDS), Bv = W0_hr hr; returns the pre-final-activation output
+__device__ __forceinline__ float mlp_forward(const float* __restrict__ a, const float (&Bv)[CF], float ox, float oy,
+                                             const float* __restrict__ W0, const float* __restrict__ W1,
+                                             const float* __restrict__ W2, const float* __restrict__ W3, float (&h0)[CF],
+                                             float (&h1)[16], float (&h2)[8]) {
+#pragma unroll
+    for (int j = 0; j < CF; j += 4) {
+        const float4 av = *reinterpret_cast<const float4*>(a + j);
+        h0[j + 0] = leaky(fmaf(W0[(j + 0) * 66 + 65], oy, fmaf(W0[(j + 0) * 66 + 64], ox, av.x + Bv[j + 0])));
+        h0[j + 1] = leaky(fmaf(W0[(j + 1) * 66 + 65], oy, fmaf(W0[(j + 1) * 66 + 64], ox, av.y + Bv[j + 1])));
+        h0[j + 2] = leaky(fmaf(W0[(j + 2) * 66 + 65], oy, fmaf(W0[(j + 2) * 66 + 64], ox, av.z + Bv[j + 2])));
+        h0[j + 3] = leaky(fmaf(W0[(j + 3) * 66 + 65], oy, fmaf(W0[(j + 3) * 66 + 64], ox, av.w + Bv[j + 3])));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < CF; ++j) acc = fmaf(W1[i * CF + j], h0[j], acc);
+        h1[i] = leaky(acc);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = fmaf(W2[i * 16 + j], h1[j], acc);
+        h2[i] = leaky(acc);
+    }
+    float o = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o = fmaf(W3[j], h2[j], o);
+    return o;
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void ecm_weights_bwd_kernel(
     const float* __restrict__ A, const float* __restrict__ hr, const float* __restrict__ W0, const float* __restrict__ W1,
-    const float* __restrict__ W2, const float* __restrict__ W3, const float* __restrict__ w9, const float* __restrict__ gw9,
-    float* __restrict__ ghr, float* __restrict__ gA9, float* __restrict__ partB, int B, int h, int w, int tiles_x) {
+    const float* __restrict__ W2, const float* __restrict__ W3, const float* __restrict__ wsaved,
+    const float* __restrict__ gw, float* __restrict__ ghr, float* __restrict__ gA9, float* __restrict__ partB, int B, int h,
+    int w, int s, int tiles_x) {
+    using NB = Nbr<VAR>;
+    constexpr int NN = NB::N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                   // [NCY*NCX][ASTRIDE]
-    float* Uall = As + NCY * NCX * ASTRIDE;             // [4 waves][64][UST]
+    float* As = smem;                                   // [NCY*ncx][ASTRIDE]
+    float* Uall = As + NCY * NCXMAX * ASTRIDE;          // [4 waves][64][UST]
     float* Rs = Uall + 4 * 64 * UST;                    // [4 waves][16 cells][32]
-    const int H = h * S, W = w * S;
+    const int H = h * s, W = w * s;
     const size_t HW = (size_t)H * W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     float* U = Uall + wave * 64 * UST;
+    const int ncx = TX / s + 2, ncell = TX / s, rbs = H / TY;      // cells per tile row, 4-row blocks per image
 
     // persistent accumulators (per wave): MFMA tiles + 8 per-lane sums for W3
     f32x4 accW1[2], accW2, accOff[2], accHr[2][2];
@@ -88,17 +122,18 @@ __global__ __launch_bounds__(256, 1) void ecm_weights9_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) accW3[i] = 0.f;
 
-    const long long ntiles = (long long)B * h * tiles_x;
+    const long long ntiles = (long long)B * rbs * tiles_x;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = (int)(tile % tiles_x);
-        const int cy = (int)((tile / tiles_x) % h);
-        const int b = (int)(tile / ((long long)tiles_x * h));
-        const int X0 = tx * TX, Y0 = cy * S;
-        const int cx0 = X0 / S - 1, cy0 = cy - 1;
+        const int rb = (int)((tile / tiles_x) % rbs);
+        const int b = (int)(tile / ((long long)tiles_x * rbs));
+        const int X0 = tx * TX, Y0 = rb * TY;
+        const int cy = Y0 / s;                            // workgroup-uniform: s % 4 == 0
+        const int cx0 = X0 / s - 1, cy0 = cy - 1;
         __syncthreads();
-        for (int e = tid; e < NCY * NCX * (CF / 4); e += 256) {
+        for (int e = tid; e < NCY * ncx * (CF / 4); e += 256) {
             const int q = e % (CF / 4), cell = e / (CF / 4);
-            const int yy = cy0 + cell / NCX, xx = cx0 + cell % NCX;
+            const int yy = cy0 + cell / ncx, xx = cx0 + cell % ncx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (yy >= 0 && yy < h && xx >= 0 && xx < w)
                 v = reinterpret_cast<const float4*>(A + (((size_t)b * h + yy) * w + xx) * CF)[q];
@@ -110,7 +145,7 @@ __global__ __launch_bounds__(256, 1) void ecm_weights9_bwd_kernel(
         const int Xc = valid ? X : W - 1;
         const size_t pix = (size_t)Y * W + Xc;
         const float* hp = hr + (size_t)b * CF * HW + pix;
-        const int cx = Xc / S, ry = wave, rx = Xc - cx * S;
+        const int cx = Xc / s, ry = Y - cy * s, rx = Xc - cx * s;
 
         float Bv[CF];
         {
@@ -125,60 +160,72 @@ __global__ __launch_bounds__(256, 1) void ecm_weights9_bwd_kernel(
                 Bv[j] = acc;
             }
         }
-        // softmax backward: gl[n] = w[n] (gw[n] - sum_m w[m] gw[m])
-        float gl[9];
-        {
-            float wv[9], dot = 0.f;
+        // gradient w.r.t. the logits
+        float gl[NN];
+        if (!NB::TIMES_LOGIT) {
+            // out = softmax(l): gl[n] = p[n] (g[n] - sum_m p[m] g[m]), p = saved output
+            float wv[NN], dot = 0.f;
 #pragma unroll
-            for (int n = 0; n < 9; ++n) {
-                wv[n] = w9[((size_t)b * 9 + n) * HW + pix];
-                gl[n] = gw9[((size_t)b * 9 + n) * HW + pix];
+            for (int n = 0; n < NN; ++n) {
+                wv[n] = wsaved[((size_t)b * NN + n) * HW + pix];
+                gl[n] = gw[((size_t)b * NN + n) * HW + pix];
                 dot = fmaf(wv[n], gl[n], dot);
             }
 #pragma unroll
-            for (int n = 0; n < 9; ++n) gl[n] = valid ? wv[n] * (gl[n] - dot) : 0.f;
+            for (int n = 0; n < NN; ++n) gl[n] = valid ? wv[n] * (gl[n] - dot) : 0.f;
+        } else {
+            // out = softmax(l) * l: recompute the logits, then gl[m] = p[m] (g[m] (l[m] + 1) - sum_n g[n] p[n] l[n])
+            float lg[NN];
+#pragma unroll 1
+            for (int n = 0; n < NN; ++n) {
+                const int yy = cy + NB::dy(n), xx = cx + NB::dx(n);
+                float v = NB::PAD;
+                if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+                    float h0[CF], h1[16], h2[8];
+                    const float* a = As + ((yy - cy0) * ncx + (xx - cx0)) * ASTRIDE;
+                    v = mlp_forward(a, Bv, ecm_off_x(NB::tab(n), rx, s), ecm_off_y(NB::tab(n), ry, s), W0, W1, W2, W3, h0, h1, h2);
+                    if (NB::FINAL_ACT) v = leaky(v);
+                }
+                lg[n] = v;
+            }
+            float m = lg[0];
+#pragma unroll
+            for (int n = 1; n < NN; ++n) m = fmaxf(m, lg[n]);
+            float p[NN], sum = 0.f;
+#pragma unroll
+            for (int n = 0; n < NN; ++n) { p[n] = expf(lg[n] - m); sum += p[n]; }
+            const float inv = 1.f / sum;
+            float dot = 0.f;
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                p[n] *= inv;
+                gl[n] = gw[((size_t)b * NN + n) * HW + pix];
+                dot = fmaf(gl[n], p[n] * lg[n], dot);
+            }
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                float g = p[n] * (gl[n] * (lg[n] + 1.f) - dot);
+                if (NB::FINAL_ACT) g *= dleaky(lg[n]);                 // through the LeakyReLU after conv3
+                gl[n] = valid ? g : 0.f;
+            }
         }
         float gBv[CF];
 #pragma unroll
         for (int j = 0; j < CF; ++j) gBv[j] = 0.f;
 
 #pragma unroll 1
-        for (int n = 0; n < 9; ++n) {
-            const int yy = cy + bDy9[n];
-            if (yy < 0 || yy >= h) continue;              // workgroup-uniform (one cell row per workgroup)
-            const int xx = cx + bDx9[n];
+        for (int n = 0; n < NN; ++n) {
+            const int yy = cy + NB::dy(n);
+            if (yy < 0 || yy >= h) continue;              // workgroup-uniform (the 4 rows share one LR cell row)
+            const int xx = cx + NB::dx(n);
             const bool inb = xx >= 0 && xx < w;
-            const float g = inb ? gl[n] : 0.f;            // out-of-image neighbours carry the constant -100: no gradient
-            const int tab = bTab9[n];
-            const float ox = offx(tab, rx), oy = offy(tab, ry);
-            const int xcl = min(max(xx, cx0), cx0 + NCX - 1);
-            const float* a = As + ((yy - cy0) * NCX + (xcl - cx0)) * ASTRIDE;
-            // ---- forward recompute --------------------------------------------------------------------
-            float h0[CF];
-#pragma unroll
-            for (int j = 0; j < CF; j += 4) {
-                const float4 av = *reinterpret_cast<const float4*>(a + j);
-                h0[j + 0] = leaky(fmaf(W0[(j + 0) * 66 + 65], oy, fmaf(W0[(j + 0) * 66 + 64], ox, av.x + Bv[j + 0])));
-                h0[j + 1] = leaky(fmaf(W0[(j + 1) * 66 + 65], oy, fmaf(W0[(j + 1) * 66 + 64], ox, av.y + Bv[j + 1])));
-                h0[j + 2] = leaky(fmaf(W0[(j + 2) * 66 + 65], oy, fmaf(W0[(j + 2) * 66 + 64], ox, av.z + Bv[j + 2])));
-                h0[j + 3] = leaky(fmaf(W0[(j + 3) * 66 + 65], oy, fmaf(W0[(j + 3) * 66 + 64], ox, av.w + Bv[j + 3])));
-            }
-            float h1[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < CF; ++j) acc = fmaf(W1[i * CF + j], h0[j], acc);
-                h1[i] = leaky(acc);
-            }
-            float h2[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc = fmaf(W2[i * 16 + j], h1[j], acc);
-                h2[i] = leaky(acc);
-            }
+            const float g = inb ? gl[n] : 0.f;            // out-of-image neighbours carry a constant: no gradient
+            const int tab = NB::tab(n);
+            const float ox = ecm_off_x(tab, rx, s), oy = ecm_off_y(tab, ry, s);
+            const int xcl = min(max(xx, cx0), cx0 + ncx - 1);
+            const float* a = As + ((yy - cy0) * ncx + (xcl - cx0)) * ASTRIDE;
+            float h0[CF], h1[16], h2[8];
+            (void)mlp_forward(a, Bv, ox, oy, W0, W1, W2, W3, h0, h1, h2);
             // ---- backward chain -----------------------------------------------------------------------
             float g2[8];
 #pragma unroll
@@ -200,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void ecm_weights9_bwd_kernel(
 #pragma unroll
             for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(U + lane * UST + 32 + j) = make_float4(g1[j], g1[j + 1], g1[j + 2], g1[j + 3]);
             wave_lds_sync();
-#pragma unroll
+#pragma unroll 4
             for (int k0 = 0; k0 < 64; k0 += 4) {
                 const float* up = U + (k0 + l4) * UST;
                 const float av = up[32 + l15];
@@ -222,34 +269,36 @@ __global__ __launch_bounds__(256, 1) void ecm_weights9_bwd_kernel(
             for (int j = 0; j < CF; j += 4) *reinterpret_cast<float4*>(U + lane * UST + j) = make_float4(h0[j], h0[j + 1], h0[j + 2], h0[j + 3]);
             *reinterpret_cast<float2*>(U + lane * UST + 32) = make_float2(ox, oy);
             wave_lds_sync();
-#pragma unroll
+#pragma unroll 4
             for (int k0 = 0; k0 < 64; k0 += 4) {
                 const float* up = U + (k0 + l4) * UST;
                 const float bvv = l15 < 2 ? up[32 + l15] : 0.f;
                 accOff[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[l15], bvv, accOff[0], 0, 0, 0);
                 accOff[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[16 + l15], bvv, accOff[1], 0, 0, 0);
             }
-            {   // lane -> (cell = lane>>2, 8 channels = (lane&3)*8..): sum the cell's 4 pixels of this row
-                const int cell = lane >> 2, j0 = (lane & 3) * 8;
-                float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+            {   // lane -> (cell = lane / s, channels j0 .. j0 + 32/s): sum the cell's s pixels of this row
+                const int cell = lane / s, nj = CF / s > 0 ? CF / s : 1, j0 = (lane % s) * nj;
+                float sum[8];
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    const float4 u0 = *reinterpret_cast<const float4*>(U + (cell * 4 + pp) * UST + j0);
-                    const float4 u1 = *reinterpret_cast<const float4*>(U + (cell * 4 + pp) * UST + j0 + 4);
-                    s0.x += u0.x; s0.y += u0.y; s0.z += u0.z; s0.w += u0.w;
-                    s1.x += u1.x; s1.y += u1.y; s1.z += u1.z; s1.w += u1.w;
+                for (int u = 0; u < 8; ++u) sum[u] = 0.f;
+                if (j0 < CF) {
+                    for (int pp = 0; pp < s; ++pp)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (u < nj) sum[u] += U[(cell * s + pp) * UST + j0 + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < nj) Rs[(wave * 16 + cell) * CF + j0 + u] = sum[u];
                 }
-                *reinterpret_cast<float4*>(Rs + (wave * 16 + cell) * CF + j0) = s0;
-                *reinterpret_cast<float4*>(Rs + (wave * 16 + cell) * CF + j0 + 4) = s1;
             }
             __syncthreads();
-            for (int e = tid; e < 16 * CF; e += 256) {       // sum the 4 rows of each cell in a fixed order
+            for (int e = tid; e < ncell * CF; e += 256) {     // sum the 4 rows of each cell in a fixed order
                 const int cell = e / CF, j = e - cell * CF;
-                const int cxs = X0 / S + cell;
+                const int cxs = X0 / s + cell;
                 if (cxs < w) {
                     const float v = (Rs[(0 * 16 + cell) * CF + j] + Rs[(1 * 16 + cell) * CF + j]) +
                                     (Rs[(2 * 16 + cell) * CF + j] + Rs[(3 * 16 + cell) * CF + j]);
-                    gA9[((((size_t)b * h + cy) * w + cxs) * 9 + n) * CF + j] = v;
+                    gA9[((((size_t)b * rbs + rb) * w + cxs) * NN + n) * CF + j] = v;
                 }
             }
             __syncthreads();
@@ -259,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void ecm_weights9_bwd_kernel(
 #pragma unroll
             for (int j = 0; j < 8; j += 4) *reinterpret_cast<float4*>(U + lane * UST + 16 + j) = make_float4(g2[j], g2[j + 1], g2[j + 2], g2[j + 3]);
             wave_lds_sync();
-#pragma unroll
+#pragma unroll 4
             for (int k0 = 0; k0 < 64; k0 += 4) {
                 const float* up = U + (k0 + l4) * UST;
                 const float av = l15 < 8 ? up[16 + l15] : 0.f;
@@ -289,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void ecm_weights9_bwd_kernel(
             for (int j = 0; j < 16; j += 4)
                 *reinterpret_cast<float4*>(U + lane * UST + 32 + j) = make_float4(hv[hs * 16 + j], hv[hs * 16 + j + 1], hv[hs * 16 + j + 2], hv[hs * 16 + j + 3]);
             wave_lds_sync();
-#pragma unroll
+#pragma unroll 4
             for (int k0 = 0; k0 < 64; k0 += 4) {
                 const float* up = U + (k0 + l4) * UST;
                 const float bvv = up[32 + l15];
@@ -328,14 +377,17 @@ __global__ __launch_bounds__(256, 1) void ecm_weights9_bwd_kernel(
         partB[(size_t)blockIdx.x * PB_N + e] = (P[e] + P[PB_N + e]) + (P[2 * PB_N + e] + P[3 * PB_N + e]);
 }
 
-// Kernel C: per LR cell.  gA = sum_n gA9[cell - d_n][n];  glr[c] = sum_j W0[j][c] gA[j];  per-workgroup
-// partial of gW0_lr[j][c] = sum_cells gA[j] lr[c].
-__global__ __launch_bounds__(128) void ecm_weights9_bwd_cells(const float* __restrict__ gA9, const float* __restrict__ lr,
-                                                              const float* __restrict__ W0, float* __restrict__ glr,
-                                                              float* __restrict__ partC, int B, int h, int w) {
+// Kernel C: per LR cell.  gA = sum_n sum_{row blocks of the source cell} gA9[rb, cell - d_n, n];
+// glr[c] = sum_j W0[j][c] gA[j];  per-workgroup partial of gW0_lr[j][c] = sum_cells gA[j] lr[c].
+template <int VAR>
+__global__ __launch_bounds__(128) void ecm_weights_bwd_cells(const float* __restrict__ gA9, const float* __restrict__ lr,
+                                                             const float* __restrict__ W0, float* __restrict__ glr,
+                                                             float* __restrict__ partC, int B, int h, int w, int s) {
+    using NB = Nbr<VAR>;
+    constexpr int NN = NB::N;
     __shared__ float Gs[128 * 33];
     __shared__ float Ls[128 * 33];
-    const int hw = h * w;
+    const int hw = h * w, rpc = s / TY, rbs = h * rpc;            // row blocks per cell / per image
     const long long i = (long long)blockIdx.x * 128 + threadIdx.x;
     const bool valid = i < (long long)B * hw;
     float gA[CF], lv[CF];
@@ -345,14 +397,17 @@ __global__ __launch_bounds__(128) void ecm_weights9_bwd_cells(const float* __res
         const int b = (int)(i / hw), p = (int)(i - (long long)b * hw);
         const int cy = p / w, cx = p - cy * w;
 #pragma unroll 1
-        for (int n = 0; n < 9; ++n) {
-            const int sy = cy - bDy9[n], sx = cx - bDx9[n];
+        for (int n = 0; n < NN; ++n) {
+            const int sy = cy - NB::dy(n), sx = cx - NB::dx(n);
             if (sy < 0 || sy >= h || sx < 0 || sx >= w) continue;
-            const float4* src = reinterpret_cast<const float4*>(gA9 + ((((size_t)b * h + sy) * w + sx) * 9 + n) * CF);
+            for (int q = 0; q < rpc; ++q) {
+                const float4* src = reinterpret_cast<const float4*>(
+                    gA9 + ((((size_t)b * rbs + sy * rpc + q) * w + sx) * NN + n) * CF);
 #pragma unroll
-            for (int q = 0; q < CF / 4; ++q) {
-                const float4 v = src[q];
-                gA[4 * q] += v.x; gA[4 * q + 1] += v.y; gA[4 * q + 2] += v.z; gA[4 * q + 3] += v.w;
+                for (int u = 0; u < CF / 4; ++u) {
+                    const float4 v = src[u];
+                    gA[4 * u] += v.x; gA[4 * u + 1] += v.y; gA[4 * u + 2] += v.z; gA[4 * u + 3] += v.w;
+                }
             }
         }
 #pragma unroll
@@ -383,8 +438,8 @@ __global__ __launch_bounds__(128) void ecm_weights9_bwd_cells(const float* __res
 }
 
 // Kernel D: gW = [gW0 (32x66) | gW1 (16x32) | gW2 (8x16) | gW3 (8)], fixed-order sums of the partials.
-__global__ void ecm_weights9_bwd_reduce(const float* __restrict__ partB, int nB, const float* __restrict__ partC, int nC,
-                                        float* __restrict__ gW) {
+__global__ void ecm_weights_bwd_reduce(const float* __restrict__ partB, int nB, const float* __restrict__ partC, int nC,
+                                       float* __restrict__ gW) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= 2760) return;
     float s = 0.f;
@@ -401,52 +456,76 @@ __global__ void ecm_weights9_bwd_reduce(const float* __restrict__ partB, int nB,
 
 struct BwdPlan { long long ntiles; int tiles_x, nB, nC; long long offA, offA9, offPB, offPC, total; };
 
-inline BwdPlan plan(int B, int h, int w) {
+inline BwdPlan plan(int B, int h, int w, int s, int nn) {
     BwdPlan p;
-    p.tiles_x = (w * S + TX - 1) / TX;
-    p.ntiles = (long long)B * h * p.tiles_x;
-    p.nB = (int)(p.ntiles < 1024 ? p.ntiles : 1024);
+    p.tiles_x = (w * s + TX - 1) / TX;
+    const long long rbs = (long long)h * s / TY;
+    p.ntiles = (long long)B * rbs * p.tiles_x;
+    p.nB = (int)(p.ntiles < 512 ? p.ntiles : 512);
     p.nC = (int)(((long long)B * h * w + 127) / 128);
     const long long cells = (long long)B * h * w;
     p.offA = 0;
     p.offA9 = p.offA + cells * CF;
-    p.offPB = p.offA9 + cells * 9 * CF;
+    p.offPB = p.offA9 + (long long)B * rbs * w * nn * CF;
     p.offPC = p.offPB + (long long)p.nB * PB_N;
     p.total = p.offPC + (long long)p.nC * 1024;
     return p;
 }
 
-constexpr int BWD_LDS_BYTES = (NCY * NCX * ASTRIDE + 4 * 64 * UST + 4 * 16 * CF) * 4;
+constexpr int BWD_LDS_BYTES = (NCY * NCXMAX * ASTRIDE + 4 * 64 * UST + 4 * 16 * CF) * 4;
+
+template <int VAR>
+int launch_bwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2, const float* W3,
+               const float* saved, const float* gout, float* glr, float* ghr, float* gW, float* base, const BwdPlan& p,
+               int B, int h, int w, int s, hipStream_t st) {
+    float *A = base + p.offA, *gA9 = base + p.offA9, *partB = base + p.offPB, *partC = base + p.offPC;
+    const long long cells = (long long)B * h * w;
+    hipLaunchKernelGGL(bwd_lr_proj, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, lr, W0, A, B, h * w);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ecm_weights_bwd_kernel<VAR>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ecm_weights_bwd_kernel<VAR>, dim3(p.nB), dim3(256), BWD_LDS_BYTES, st, A, hr, W0, W1, W2, W3, saved,
+                       gout, ghr, gA9, partB, B, h, w, s, p.tiles_x);
+    hipLaunchKernelGGL(ecm_weights_bwd_cells<VAR>, dim3(p.nC), dim3(128), 0, st, gA9, lr, W0, glr, partC, B, h, w, s);
+    hipLaunchKernelGGL(ecm_weights_bwd_reduce, dim3((2760 + 255) / 256), dim3(256), 0, st, partB, p.nB, partC, p.nC, gW);
+    return ECM_LAUNCH_RESULT();
+}
+
+inline int planes_of(int variant) { return variant == 0 ? 9 : variant == 1 ? 5 : 3; }
 
 }  // namespace
 
+extern "C" long long ecm_context_weights_bwd_scratch_bytes(int B, int h, int w, int s, int variant) {
+    if (B <= 0 || h <= 0 || w <= 0 || s < 4 || s % 4 != 0 || s > 64 || variant < 0 || variant > 2) return 0;
+    return plan(B, h, w, s, planes_of(variant)).total * (long long)sizeof(float);
+}
+
+extern "C" int ecm_context_weights_bwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2,
+                                       const float* W3, const float* out_saved, const float* gout, float* glr, float* ghr,
+                                       float* gW, void* scratch, long long scratch_bytes, int B, int h, int w, int s,
+                                       int variant, void* stream) {
+    ECM_CHECK_ARG(lr && hr && W0 && W1 && W2 && W3 && out_saved && gout && glr && ghr && gW && scratch && B > 0 && h > 0 && w > 0);
+    if (s < 4 || s % 4 != 0 || s > 64 || variant < 0 || variant > 2) return ECM_EUNSUP;
+    const BwdPlan p = plan(B, h, w, s, planes_of(variant));
+    if (scratch_bytes < p.total * (long long)sizeof(float)) return ECM_ESCRATCH;
+    float* base = static_cast<float*>(scratch);
+    hipStream_t st = ecm_stream(stream);
+    if (variant == 0) return launch_bwd<0>(lr, hr, W0, W1, W2, W3, out_saved, gout, glr, ghr, gW, base, p, B, h, w, s, st);
+    if (variant == 1) return launch_bwd<1>(lr, hr, W0, W1, W2, W3, out_saved, gout, glr, ghr, gW, base, p, B, h, w, s, st);
+    return launch_bwd<2>(lr, hr, W0, W1, W2, W3, out_saved, gout, glr, ghr, gW, base, p, B, h, w, s, st);
+}
+
 extern "C" long long ecm_weights9_bwd_scratch_bytes(int B, int h, int w, int s) {
-    if (B <= 0 || h <= 0 || w <= 0 || s != S) return 0;
-    return plan(B, h, w).total * (long long)sizeof(float);
+    return ecm_context_weights_bwd_scratch_bytes(B, h, w, s, 0);
 }
 
 extern "C" int ecm_weights9_bwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2,
                                 const float* W3, const float* w9, const float* gw9, float* glr, float* ghr, float* gW,
                                 void* scratch, long long scratch_bytes, int B, int h, int w, int s, void* stream) {
-    ECM_CHECK_ARG(lr && hr && W0 && W1 && W2 && W3 && w9 && gw9 && glr && ghr && gW && scratch && B > 0 && h > 0 && w > 0);
-    if (s != S) return ECM_EUNSUP;
-    const BwdPlan p = plan(B, h, w);
-    if (scratch_bytes < p.total * (long long)sizeof(float)) return ECM_ESCRATCH;
-    float* base = static_cast<float*>(scratch);
-    float *A = base + p.offA, *gA9 = base + p.offA9, *partB = base + p.offPB, *partC = base + p.offPC;
-    hipStream_t st = ecm_stream(stream);
-    const long long cells = (long long)B * h * w;
-    hipLaunchKernelGGL(bwd_lr_proj, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, lr, W0, A, B, h * w);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ecm_weights9_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(ecm_weights9_bwd_kernel, dim3(p.nB), dim3(256), BWD_LDS_BYTES, st, A, hr, W0, W1, W2, W3, w9, gw9, ghr,
-                       gA9, partB, B, h, w, p.tiles_x);
-    hipLaunchKernelGGL(ecm_weights9_bwd_cells, dim3(p.nC), dim3(128), 0, st, gA9, lr, W0, glr, partC, B, h, w);
-    hipLaunchKernelGGL(ecm_weights9_bwd_reduce, dim3((2760 + 255) / 256), dim3(256), 0, st, partB, p.nB, partC, p.nC, gW);
-    return ECM_LAUNCH_RESULT();
+    return ecm_context_weights_bwd(lr, hr, W0, W1, W2, W3, w9, gw9, glr, ghr, gW, scratch, scratch_bytes, B, h, w, s, 0,
+                                   stream);
 }

@@ -214,11 +214,26 @@ class ContextWeights(torch.autograd.Function):
         scratch = _scratch(nb, lr.device)
         _lib.call("ecm_context_weights_fwd", _p(lr), _p(hr), _p(W0), _p(W1), _p(W2), _p(W3), _p(out), _p(scratch),
                   C.c_longlong(nb), B, h, w, s, variant, _stream())
+        ctx.save_for_backward(lr, hr, W0, W1, W2, W3, out)
+        ctx.s, ctx.variant = s, variant
         return out
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError("six_related context weights: backward kernel not built yet (forward/inference only)")
+        lr, hr, W0, W1, W2, W3, out = ctx.saved_tensors
+        B, _, h, w = lr.shape
+        s, variant = ctx.s, ctx.variant
+        g = _c(g)
+        glr, ghr = torch.empty_like(lr), torch.empty_like(hr)
+        gW = torch.empty(2112 + 512 + 128 + 8, device=lr.device, dtype=lr.dtype)
+        nb = _lib.query("ecm_context_weights_bwd_scratch_bytes", B, h, w, s, variant)
+        if nb == 0:
+            raise RuntimeError(f"context_weights backward: unsupported scale {s} (needs s % 4 == 0)")
+        scratch = _scratch(nb, lr.device)
+        _lib.call("ecm_context_weights_bwd", _p(lr), _p(hr), _p(W0), _p(W1), _p(W2), _p(W3), _p(out), _p(g), _p(glr),
+                  _p(ghr), _p(gW), _p(scratch), C.c_longlong(nb), B, h, w, s, variant, _stream())
+        return (glr, ghr, gW[:2112].view_as(W0), gW[2112:2624].view_as(W1), gW[2624:2752].view_as(W2),
+                gW[2752:].view_as(W3), None)
 
 
 def context_weights(lr, hr, W0, W1, W2, W3, variant):

@@ -83,6 +83,14 @@ int ecm_context_weights_fwd(const float* lr, const float* hr, const float* W0, c
                             const float* W3, float* out, void* scratch, long long scratch_bytes,
                             int B, int h, int w, int s, int variant, void* stream);
 
+/* Backward of ecm_context_weights_fwd for any variant and any scale with s % 4 == 0.  out_saved = the forward output
+ * (used by variant 0; variants 1/2 recompute their logits).  gW = [gW0(2112) | gW1(512) | gW2(128) | gW3(8)] floats. */
+long long ecm_context_weights_bwd_scratch_bytes(int B, int h, int w, int s, int variant);
+int ecm_context_weights_bwd(const float* lr, const float* hr, const float* W0, const float* W1, const float* W2,
+                            const float* W3, const float* out_saved, const float* gout,
+                            float* glr, float* ghr, float* gW, void* scratch, long long scratch_bytes,
+                            int B, int h, int w, int s, int variant, void* stream);
+
 /* ---- a10: volume mapping head (cmfsm_sub_16.py:767-801 [+804-848], cm_sub_8.py:765-800), fused: NN-upsample of the LR
  * logits in D,H,W, 5-neighbour spatial fuse with m5 [B,5,H,W] (c,r,l,t,b), three target-weight volumes built from
  * mt3 [B,3,H,W] (c,r,l) shifted by the disparity, +-s fuse along D, softmax over D = Dl*s, regression.

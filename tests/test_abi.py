@@ -55,7 +55,8 @@ def test_size_queries_need_no_gpu(lib_mod):
     assert lib_mod.query("ecm_weights9_scratch_bytes", 1, 144, 240) == 144 * 240 * 32 * 4
     assert lib_mod.query("ecm_gn3d_scratch_bytes", 1, 32, ctypes.c_longlong(48 * 144 * 240)) > 0
     assert lib_mod.query("ecm_weights9_bwd_scratch_bytes", 1, 8, 12, 4) > 0
-    assert lib_mod.query("ecm_weights9_bwd_scratch_bytes", 1, 8, 12, 8) == 0          # unsupported scale
+    assert lib_mod.query("ecm_weights9_bwd_scratch_bytes", 1, 8, 12, 6) == 0          # unsupported scale (s % 4 != 0)
+    assert lib_mod.query("ecm_context_weights_bwd_scratch_bytes", 1, 8, 12, 8, 1) > 0
 
 
 def test_null_pointers_are_rejected_without_touching_the_gpu(lib_mod):

@@ -371,6 +371,26 @@ def test_six_related_weights_vs_oracle(ecm, cmfsm_sd, B, h, w, s):
     close(mt3, rmt3, 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("B,h,w,s", [(1, 4, 8, 8), (2, 3, 17, 4), (1, 2, 4, 16)])
+def test_six_related_weights_bwd_vs_oracle(ecm, cmfsm_sd, B, h, w, s):
+    lr, hr = seeded("sxb.lr", B, 32, h, w), seeded("sxb.hr", B, 32, h * s, w * s)
+    lr_r, hr_r = seeded("sxb.lr_r", B, 32, h, w), seeded("sxb.hr_r", B, 32, h * s, w * s)
+    G5, G3 = seeded("sxb.G5", B, 5, h * s, w * s), seeded("sxb.G3", B, 3, h * s, w * s)
+    tg = [dev(t).requires_grad_() for t in (lr, hr, lr_r, hr_r)]
+    Ws = [dev(t).requires_grad_() for t in _mlp(cmfsm_sd)]
+    m5 = ecm.ops.context_weights(tg[0], tg[1], *Ws, 1)
+    mt3 = ecm.ops.context_weights(tg[2], tg[3], *Ws, 2)
+    ((m5 * dev(G5)).sum() + (mt3 * dev(G3)).sum()).backward()
+    sd = {k: v.clone().requires_grad_() for k, v in cmfsm_sd.items() if k.startswith("mapping_matrix")}
+    tc = [t.clone().requires_grad_() for t in (lr, hr, lr_r, hr_r)]
+    rm5, rmt3 = O.ecm_weights_six(*tc, sd)
+    ((rm5 * G5).sum() + (rmt3 * G3).sum()).backward()
+    for a, b_ in zip(tg, tc):
+        close(a.grad, b_.grad, 2e-3, 2e-5)
+    for i in range(4):
+        close(Ws[i].grad, sd[f"mapping_matrix.similarity1.conv{i}.weight"].grad, 2e-3, 2e-4)
+
+
 @pytest.mark.parametrize("NH,B,Dl,h,w,s", [(1, 1, 12, 4, 4, 16), (3, 1, 12, 3, 5, 16), (1, 2, 24, 4, 8, 8), (2, 1, 48, 4, 8, 4)])
 def test_volume_mapping_vs_oracle(ecm, NH, B, Dl, h, w, s):
     c = seeded("vm.c", NH, B, Dl, h, w, scale=1.5)

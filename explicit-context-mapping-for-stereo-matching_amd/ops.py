@@ -253,11 +253,19 @@ class VolumeMapping(torch.autograd.Function):
         out = torch.empty(NH, B, h * scale, w * scale, device=c.device, dtype=c.dtype)
         _lib.call("ecm_volume_mapping_fwd", _p(c), C.c_longlong(B * Dl * h * w), _p(m5), _p(mt3), _p(out), NH, B, Dl, h, w,
                   scale, _stream())
+        ctx.save_for_backward(c, m5, mt3)
+        ctx.scale = scale
         return out
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError("volume-mapping head: backward kernel not built yet (forward/inference only)")
+        c, m5, mt3 = ctx.saved_tensors
+        NH, B, Dl, h, w = c.shape
+        g = _c(g)
+        gc, gm5, gmt3 = torch.empty_like(c), torch.empty_like(m5), torch.empty_like(mt3)
+        _lib.call("ecm_volume_mapping_bwd", _p(c), C.c_longlong(B * Dl * h * w), _p(m5), _p(mt3), _p(g), _p(gc), _p(gm5),
+                  _p(gmt3), NH, B, Dl, h, w, ctx.scale, _stream())
+        return gc, gm5, gmt3, None
 
 
 def volume_mapping(c, m5, mt3, scale):
@@ -275,11 +283,20 @@ class TrilinearSoftArgmin(torch.autograd.Function):
         out = torch.empty(NH, B, H, W, device=c.device, dtype=c.dtype)
         _lib.call("ecm_trilinear_softargmin_fwd", _p(c), C.c_longlong(B * Dl * h * w), _p(out), NH, B, Dl, h, w, Do, H, W,
                   _stream())
+        ctx.save_for_backward(c)
+        ctx.dims = (Do, H, W)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError("trilinear head: backward kernel not built yet (forward/inference only)")
+        (c,) = ctx.saved_tensors
+        NH, B, Dl, h, w = c.shape
+        Do, H, W = ctx.dims
+        g = _c(g)
+        gc = torch.empty_like(c)
+        _lib.call("ecm_trilinear_softargmin_bwd", _p(c), C.c_longlong(B * Dl * h * w), _p(g), _p(gc), NH, B, Dl, h, w, Do, H,
+                  W, _stream())
+        return gc, None, None, None
 
 
 def trilinear_softargmin(c, Do, H, W):

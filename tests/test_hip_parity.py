@@ -396,18 +396,29 @@ def test_volume_mapping_vs_oracle(ecm, NH, B, Dl, h, w, s):
     c = seeded("vm.c", NH, B, Dl, h, w, scale=1.5)
     m5 = seeded("vm.m5", B, 5, h * s, w * s, scale=0.5)
     mt3 = seeded("vm.mt3", B, 3, h * s, w * s, scale=0.5)
-    out = ecm.ops.volume_mapping(dev(c), dev(m5), dev(mt3), s)
-    ref = torch.stack([O.volume_mapping(c[:k + 1].sum(0), m5, mt3, s, Dl * s) for k in range(NH)], 0)
+    tg = [dev(t).requires_grad_() for t in (c, m5, mt3)]
+    out = ecm.ops.volume_mapping(*tg, s)
+    tc = [t.clone().requires_grad_() for t in (c, m5, mt3)]
+    ref = torch.stack([O.volume_mapping(tc[0][:k + 1].sum(0), tc[1], tc[2], s, Dl * s) for k in range(NH)], 0)
     close(out, ref, 1e-4, 2e-4)
+    G = seeded("vm.G", *ref.shape)
+    out.backward(dev(G)); ref.backward(G)
+    for a, b_ in zip(tg, tc):
+        close(a.grad, b_.grad, 2e-3, 2e-3 * float(b_.grad.abs().max()))
 
 
 @pytest.mark.parametrize("NH,B,Dl,h,w,Do,H,W", [(1, 1, 48, 4, 8, 192, 16, 32), (3, 2, 12, 3, 5, 192, 48, 80),
                                                (2, 1, 24, 4, 6, 192, 30, 50)])
 def test_trilinear_head_vs_oracle(ecm, NH, B, Dl, h, w, Do, H, W):
     c = seeded("tl.c", NH, B, Dl, h, w, scale=1.5)
-    out = ecm.ops.trilinear_softargmin(dev(c), Do, H, W)
-    ref = torch.stack([O.trilinear_head(c[:k + 1].sum(0), Do, H, W) for k in range(NH)], 0)
+    cg = dev(c).requires_grad_()
+    out = ecm.ops.trilinear_softargmin(cg, Do, H, W)
+    cc = c.clone().requires_grad_()
+    ref = torch.stack([O.trilinear_head(cc[:k + 1].sum(0), Do, H, W) for k in range(NH)], 0)
     close(out, ref, 1e-4, 2e-4)
+    G = seeded("tl.G", *ref.shape)
+    out.backward(dev(G)); ref.backward(G)
+    close(cg.grad, cc.grad, 2e-3, 2e-3 * float(cc.grad.abs().max()))
 
 
 @pytest.mark.parametrize("arch", list(ARCHS))
@@ -420,12 +431,27 @@ def test_arch_hot_path_golden(ecm, arch):
     assert not unexpected and all(k.startswith("feature_extraction") for k in missing)
     model = model.cuda()
     lr_l, hr_l, lr_r, hr_r = (dev(t) for t in arch_inputs(arch))
-    with torch.no_grad():
-        preds = model.hot_path(lr_l, hr_l, lr_r, hr_r)
+    for t_ in (lr_l, hr_l, lr_r, hr_r):
+        t_.requires_grad_()
+    preds = model.hot_path(lr_l, hr_l, lr_r, hr_r)
     for i, p in enumerate(preds, 1):
         assert p.shape == g[f"pred{i}"].shape, (arch, p.shape, g[f"pred{i}"].shape)
-        d = (p.cpu() - g[f"pred{i}"]).abs()
+        d = (p.detach().cpu() - g[f"pred{i}"]).abs()
         assert d.max() <= 2e-2 and d.mean() <= 1e-3, (arch, i, d.max(), d.mean())
+    # backward of the whole path vs the gradients the reference's autograd produced
+    loss = sum((p * dev(seeded(f"{arch}.G{i}", *p.shape))).sum() for i, p in enumerate(preds))
+    loss.backward()
+    for nm, t_ in (("g_lr_l", lr_l), ("g_hr_l", hr_l), ("g_lr_r", lr_r), ("g_hr_r", hr_r)):
+        if nm in g:
+            ref = g[nm]
+            tol = 2e-2 * float(ref.abs().max()) + 1e-6
+            assert (t_.grad.cpu() - ref).abs().max() <= tol, (arch, nm, float((t_.grad.cpu() - ref).abs().max()), tol)
+    for k, v in model.named_parameters():
+        if k.startswith("feature_extraction"):
+            continue
+        ref_norm = float(g["gn_" + k.replace(".", "_")])
+        got = float(v.grad.norm()) if v.grad is not None else 0.0
+        assert abs(got - ref_norm) <= 2e-2 * ref_norm + 1e-5, (arch, k, got, ref_norm)
 
 
 def test_arch_state_dict_contracts(ecm):

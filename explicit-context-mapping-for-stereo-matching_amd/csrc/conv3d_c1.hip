@@ -1,0 +1,284 @@
+// The classifier's last layer, Conv3d(32 -> 1, k3, pad 1, no bias) (reference classif1/2/3[2], cmfsm.py:624,629,634),
+// forward and weight gradient.  With ONE output channel the generic implicit GEMM wastes 31/32 of every MFMA, so the
+// contraction is re-associated:
+//   forward:  T[tap][u] = sum_ci w[ci,tap] x[ci,u]   (a 27 x Ci x voxels GEMM on the fp32 matrix cores, M = taps),
+//             y[v] = sum_tap T[tap][v + off(tap)]     (27 shifted adds out of LDS, fixed order => deterministic)
+//   wgrad:    gw[ci,tap] = sum_u x[ci,u] * gy[u - off(tap)]  (M = ci, N = taps, K = voxels: one MFMA per two voxels
+//             covers all 32 x 27 products; the tap shift is a per-lane LDS offset on the small gy tile)
+// Both are then bound by reading x once (212 MB at 576x960) instead of by ~92 GFLOP of padded MFMA work.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------ forward
+constexpr int FTD = 2, FTH = 4, FTW = 30;                  // output tile; input tile (FTD+2) x (FTH+2) rows of 32 columns
+constexpr int FID = FTD + 2, FIH = FTH + 2, FROWS = FID * FIH;          // 24 input rows
+constexpr int FRW = FROWS / 4;                                           // rows per wave
+constexpr int FCIC = 8;                                                  // input channels per staged chunk
+constexpr int F_XS = FCIC * FROWS * 32;                                  // staged x floats
+constexpr int F_TS = 27 * FROWS * 32;                                    // T image floats  [tap][row][32]
+constexpr int F_LDS_BYTES = (F_XS + F_TS) * 4;
+
+__global__ __launch_bounds__(256) void conv3d_c1_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                     float* __restrict__ y, int Ci, int D, int H, int W, int tiles_d,
+                                                     int tiles_h, int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                 // [FCIC][FROWS][32]
+    float* Ts = smem + F_XS;          // [27][FROWS][32]
+    int bid = blockIdx.x;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h; bid /= tiles_h;
+    const int td = bid % tiles_d;
+    const int b = bid / tiles_d;
+    const int od0 = td * FTD, oh0 = th * FTH, ow0 = tw * FTW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
+    const float* xb = x + (size_t)b * Ci * DHW;
+
+    // A operand (weights) for every k-step, kept in registers: lane holds w[ci = 2*kk + half][tap = l31]
+    float wa[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int ci = 2 * kk + half;
+        wa[kk] = (l31 < 27 && ci < Ci) ? w[(size_t)ci * 27 + l31] : 0.f;
+    }
+    // staging: thread owns 3 fixed (row, column) positions of the 24 x 32 input window (768 = 3 x 256)
+    unsigned posoff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int p = tid + j * 256;
+        const int xx = p & 31, row = p >> 5;
+        const int dz = row / FIH, hy = row - dz * FIH;
+        const int gz = od0 - 1 + dz, gy = oh0 - 1 + hy, gx = ow0 - 1 + xx;
+        const bool ok = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        posoff[j] = ok ? (unsigned)(gz * (int)HW + gy * W + gx) * 4u : 0x80000000u;
+    }
+    const unsigned plane_bytes = (unsigned)DHW * 4u;
+    float xr[FCIC * 3];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int cc = 0; cc < FCIC; ++cc) {
+            const bool cok = c0 + cc < Ci;
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(cok ? c0 + cc : 0) * DHW), 0,
+                                                                cok ? plane_bytes : 0u, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                xr[cc * 3 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, posoff[j], 0, 0));
+        }
+    };
+    f32x16 acc[FRW];
+#pragma unroll
+    for (int r = 0; r < FRW; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+
+    prefetch(0);
+    for (int c0 = 0; c0 < Ci; c0 += FCIC) {
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < FCIC; ++cc)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Xs[cc * FROWS * 32 + tid + j * 256] = xr[cc * 3 + j];
+        __syncthreads();
+        if (c0 + FCIC < Ci) prefetch(c0 + FCIC);
+#pragma unroll
+        for (int kk = 0; kk < FCIC / 2; ++kk) {
+            // wa index of this chunk's k-step: channels c0 + 2*kk + half  (c0 is a multiple of 8 => static within 32)
+            float a;
+            switch (c0 >> 3) {
+                case 0: a = wa[kk]; break;
+                case 1: a = wa[4 + kk]; break;
+                case 2: a = wa[8 + kk]; break;
+                default: a = wa[12 + kk]; break;
+            }
+#pragma unroll
+            for (int r = 0; r < FRW; ++r) {
+                const float bv = Xs[((kk * 2 + half) * FROWS + wave * FRW + r) * 32 + l31];
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[r], 0, 0, 0);
+            }
+        }
+    }
+    // T[tap][row][x] -> LDS   (D fragment: column = x, register i = tap (i&3) + 8*(i>>2) + 4*half)
+#pragma unroll
+    for (int r = 0; r < FRW; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int tap = (i & 3) + 8 * (i >> 2) + 4 * half;
+            if (tap < 27) Ts[(tap * FROWS + wave * FRW + r) * 32 + l31] = acc[r][i];
+        }
+    __syncthreads();
+    // y[dz,hy,x] = sum_tap T[tap][(dz+kd, hy+kh)][x+kw]   -- 240 outputs, one per thread, taps in fixed order
+    if (tid < FTD * FTH * FTW) {
+        const int xo = tid % FTW, hy = (tid / FTW) % FTH, dz = tid / (FTW * FTH);
+        const int od = od0 + dz, oh = oh0 + hy, ow = ow0 + xo;
+        if (od < D && oh < H && ow < W) {
+            float s = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) {
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                s += Ts[(tap * FROWS + (dz + kd) * FIH + hy + kh) * 32 + xo + kw];
+            }
+            y[(size_t)b * DHW + (size_t)od * HW + (size_t)oh * W + ow] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+constexpr int GTD = 2, GTH = 8, GTW = 32, GNV = GTD * GTH * GTW;       // 512 voxels of x per tile (no halo on x)
+constexpr int GXSTR = GNV + 1;                                           // odd channel stride: 32 lanes (ci) -> 32 banks
+constexpr int GRS = 35, GPS = 361;                                       // gy halo row / plane strides: 3 and 9 (mod 32)
+constexpr int G_GYF = (GTD + 2) * GPS;                                   //   => the 27 tap offsets hit 27 distinct banks
+constexpr int G_LDS_BYTES = (32 * GXSTR + G_GYF + 4 * 1024) * 4;
+static_assert((GTH + 2) * GRS <= GPS, "plane stride too small");
+
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
+                                                       float* __restrict__ partial, int B, int Ci, int D, int H, int W,
+                                                       int tiles_d, int tiles_h, int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                       // [32 ci][GXSTR]
+    float* Gs = smem + 32 * GXSTR;          // gy halo tile [(GTD+2)][GPS] (rows of GRS)
+    float* Ps = Gs + G_GYF;                 // [4 waves][1024] end-of-kernel reduction
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
+    // lane's tap (B operand column) and its offset inside the gy halo tile relative to the voxel's own position
+    const int tap = l31 < 27 ? l31 : 0;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    // x voxel u=(dz,hy,xx) pairs with gy[u - (tap-1)]; the halo tile starts one voxel before the tile, so that is
+    // halo index (dz+2-kd, hy+2-kh, xx+2-kw)
+    const int toff = (2 - kd) * GPS + (2 - kh) * GRS + (2 - kw);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const unsigned xplane = (unsigned)DHW * 4u;
+    const long long ntiles = (long long)B * tiles_d * tiles_h * tiles_w;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long long r = tile;
+        const int tw = (int)(r % tiles_w); r /= tiles_w;
+        const int th = (int)(r % tiles_h); r /= tiles_h;
+        const int td = (int)(r % tiles_d);
+        const int b = (int)(r / tiles_d);
+        const int d0 = td * GTD, h0 = th * GTH, w0 = tw * GTW;
+        __syncthreads();
+        // x tile: 32 channels x 512 voxels (2 per thread per channel), zero outside the volume
+        {
+            unsigned off[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int v = tid + j * 256;
+                const int xx = v % GTW, hy = (v / GTW) % GTH, dz = v / (GTW * GTH);
+                const int gz = d0 + dz, gyy = h0 + hy, gx = w0 + xx;
+                const bool ok = gz < D && gyy < H && gx < W;
+                off[j] = ok ? (unsigned)(gz * (int)HW + gyy * W + gx) * 4u : 0x80000000u;
+            }
+            const int nci = Ci < 32 ? Ci : 32;
+            const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * Ci * DHW), 0,
+                                                               (unsigned)nci * xplane, 0x00020000);
+#pragma unroll 8
+            for (int cc = 0; cc < 32; ++cc)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    Xs[cc * GXSTR + tid + j * 256] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off[j] + (unsigned)cc * xplane, 0, 0));
+        }
+        // gy halo tile (GTD+2) x (GTH+2) x (GTW+2), zero outside
+        for (int e = tid; e < (GTD + 2) * (GTH + 2) * (GTW + 2); e += 256) {
+            const int xx = e % (GTW + 2), hy = (e / (GTW + 2)) % (GTH + 2), dz = e / ((GTW + 2) * (GTH + 2));
+            const int gz = d0 - 1 + dz, gyy = h0 - 1 + hy, gx = w0 - 1 + xx;
+            float v = 0.f;
+            if ((unsigned)gz < (unsigned)D && (unsigned)gyy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v = gy[(size_t)b * DHW + (size_t)gz * HW + (size_t)gyy * W + gx];
+            Gs[dz * GPS + hy * GRS + xx] = v;
+        }
+        __syncthreads();
+        // k-steps: two x-adjacent voxels; wave handles rows {wave, wave+4, ...} of the 16 tile rows
+        const float* xa = Xs + l31 * GXSTR + half;
+        const float* gb = Gs + toff + half;
+#pragma unroll
+        for (int rr = 0; rr < GTD * GTH / 4; ++rr) {
+            const int row = wave + rr * 4;
+            const int dz = row / GTH, hy = row % GTH;
+#pragma unroll
+            for (int xx = 0; xx < GTW; xx += 2) {
+                const float a = xa[(dz * GTH + hy) * GTW + xx];
+                const float bv = l31 < 27 ? gb[dz * GPS + hy * GRS + xx] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+            }
+        }
+    }
+    // D[ci][tap]: column = tap = l31, rows ci = (i&3) + 8*(i>>2) + 4*half.  Sum the 4 waves, then one partial per block.
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ci = (i & 3) + 8 * (i >> 2) + 4 * half;
+        Ps[wave * 1024 + ci * 32 + l31] = acc[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+        const int ci = e >> 5, t = e & 31;
+        if (t < 27 && ci < Ci)
+            partial[(size_t)blockIdx.x * Ci * 27 + ci * 27 + t] = (Ps[e] + Ps[1024 + e]) + (Ps[2048 + e] + Ps[3072 + e]);
+    }
+}
+
+__global__ void c1_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, int n, int P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partial[(size_t)p * n + i];
+    gw[i] = s;
+}
+
+inline int c1_workers(long long ntiles) { return (int)(ntiles < 512 ? ntiles : 512); }
+inline long long c1_tiles(int B, int D, int H, int W) {
+    return (long long)B * ((D + GTD - 1) / GTD) * ((H + GTH - 1) / GTH) * ((W + GTW - 1) / GTW);
+}
+
+}  // namespace
+
+extern "C" int ecm_conv3d_c1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, void* stream) {
+    ECM_CHECK_ARG(x && w && y && B > 0 && Ci > 0 && D > 0 && H > 0 && W > 0);
+    if (Ci > 32 || Ci % FCIC != 0 || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
+    const int tiles_d = (D + FTD - 1) / FTD, tiles_h = (H + FTH - 1) / FTH, tiles_w = (W + FTW - 1) / FTW;
+    const long long nblk = (long long)B * tiles_d * tiles_h * tiles_w;
+    if (nblk > 0x7fffffffLL) return ECM_EUNSUP;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c1_fwd),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3d_c1_fwd, dim3((unsigned)nblk), dim3(256), F_LDS_BYTES, ecm_stream(stream), x, w, y, Ci, D, H, W,
+                       tiles_d, tiles_h, tiles_w);
+    return ECM_LAUNCH_RESULT();
+}
+
+extern "C" long long ecm_conv3d_c1_wgrad_scratch_bytes(int B, int Ci, int D, int H, int W) {
+    if (B <= 0 || Ci <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return (long long)c1_workers(c1_tiles(B, D, H, W)) * Ci * 27 * (long long)sizeof(float);
+}
+
+extern "C" int ecm_conv3d_c1_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B,
+                                   int Ci, int D, int H, int W, void* stream) {
+    ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && D > 0 && H > 0 && W > 0);
+    if (Ci > 32 || (long long)D * H * W * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;
+    if (scratch_bytes < ecm_conv3d_c1_wgrad_scratch_bytes(B, Ci, D, H, W)) return ECM_ESCRATCH;
+    const int tiles_d = (D + GTD - 1) / GTD, tiles_h = (H + GTH - 1) / GTH, tiles_w = (W + GTW - 1) / GTW;
+    const int P = c1_workers(c1_tiles(B, D, H, W));
+    hipStream_t st = ecm_stream(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c1_wgrad),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    float* partial = static_cast<float*>(scratch);
+    hipLaunchKernelGGL(conv3d_c1_wgrad, dim3(P), dim3(256), G_LDS_BYTES, st, x, gy, partial, B, Ci, D, H, W, tiles_d, tiles_h,
+                       tiles_w);
+    const int n = Ci * 27;
+    hipLaunchKernelGGL(c1_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, n, P);
+    return ECM_LAUNCH_RESULT();
+}

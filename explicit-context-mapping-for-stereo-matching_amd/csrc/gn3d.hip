@@ -115,12 +115,30 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_partial(const float* __restric
     const long long beg = (long long)blockIdx.x * CHUNK;
     const long long end = beg + CHUNK < S ? beg + CHUNK : S;
     float sg = 0.f, sgx = 0.f;
-    for (long long i = beg + threadIdx.x; i < end; i += THREADS) {
-        float gv = gy[base + i];
-        if (RELU && !(y[base + i] > 0.f)) gv = 0.f;
-        if (gskip) gskip[base + i] = gv;
-        sg += gv;
-        sgx += gv * ((x[base + i] - mean) * rstd);
+    if ((S & 3) == 0) {
+        for (long long i = beg + threadIdx.x * 4; i < end; i += THREADS * 4) {
+            float4 gv = *reinterpret_cast<const float4*>(gy + base + i);
+            if (RELU) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+                if (!(yv.x > 0.f)) gv.x = 0.f;
+                if (!(yv.y > 0.f)) gv.y = 0.f;
+                if (!(yv.z > 0.f)) gv.z = 0.f;
+                if (!(yv.w > 0.f)) gv.w = 0.f;
+            }
+            if (gskip) *reinterpret_cast<float4*>(gskip + base + i) = gv;
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+            sg += (gv.x + gv.y) + (gv.z + gv.w);
+            sgx += (gv.x * ((xv.x - mean) * rstd) + gv.y * ((xv.y - mean) * rstd)) +
+                   (gv.z * ((xv.z - mean) * rstd) + gv.w * ((xv.w - mean) * rstd));
+        }
+    } else {
+        for (long long i = beg + threadIdx.x; i < end; i += THREADS) {
+            float gv = gy[base + i];
+            if (RELU && !(y[base + i] > 0.f)) gv = 0.f;
+            if (gskip) gskip[base + i] = gv;
+            sg += gv;
+            sgx += gv * ((x[base + i] - mean) * rstd);
+        }
     }
     block_reduce2(sg, sgx, sm);
     if (threadIdx.x == 0) {
@@ -169,11 +187,31 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_apply(const float* __restrict_
     const float invn = 1.f / ((float)cpg * (float)S);
     const float gm = gamma[c], k1 = s1 * invn, k2 = s2 * invn;
     const size_t base = (size_t)bc * S;
-    for (long long i = (long long)blockIdx.x * THREADS + threadIdx.x; i < S; i += (long long)gridDim.x * THREADS) {
-        float gv = gy[base + i];
-        if (RELU && !(y[base + i] > 0.f)) gv = 0.f;
-        const float xh = (x[base + i] - mean) * rstd;
-        gx[base + i] = rstd * (gv * gm - k1 - xh * k2);
+    if ((S & 3) == 0) {
+        for (long long i = ((long long)blockIdx.x * THREADS + threadIdx.x) * 4; i < S; i += (long long)gridDim.x * THREADS * 4) {
+            float4 gv = *reinterpret_cast<const float4*>(gy + base + i);
+            if (RELU) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+                if (!(yv.x > 0.f)) gv.x = 0.f;
+                if (!(yv.y > 0.f)) gv.y = 0.f;
+                if (!(yv.z > 0.f)) gv.z = 0.f;
+                if (!(yv.w > 0.f)) gv.w = 0.f;
+            }
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+            float4 o;
+            o.x = rstd * (gv.x * gm - k1 - ((xv.x - mean) * rstd) * k2);
+            o.y = rstd * (gv.y * gm - k1 - ((xv.y - mean) * rstd) * k2);
+            o.z = rstd * (gv.z * gm - k1 - ((xv.z - mean) * rstd) * k2);
+            o.w = rstd * (gv.w * gm - k1 - ((xv.w - mean) * rstd) * k2);
+            *reinterpret_cast<float4*>(gx + base + i) = o;
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * THREADS + threadIdx.x; i < S; i += (long long)gridDim.x * THREADS) {
+            float gv = gy[base + i];
+            if (RELU && !(y[base + i] > 0.f)) gv = 0.f;
+            const float xh = (x[base + i] - mean) * rstd;
+            gx[base + i] = rstd * (gv * gm - k1 - xh * k2);
+        }
     }
 }
 
@@ -235,8 +273,8 @@ extern "C" int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float*
     else hipLaunchKernelGGL(gn_bwd_partial<false>, g1, block, 0, st, x, mean_rstd, y, gy, gskip, part, C, S, nchunks);
     hipLaunchKernelGGL(gn_bwd_final_chan, dim3((B * C + 63) / 64), dim3(64), 0, st, part, chan, B * C, nchunks);
     hipLaunchKernelGGL(gn_bwd_params, dim3((C + 63) / 64), dim3(64), 0, st, chan, ggamma, gbeta, B, C);
-    long long per = (S + THREADS - 1) / THREADS;
-    dim3 g2((int)(per < 128 ? per : 128), B * C);
+    long long per = (S + THREADS * 4 - 1) / (THREADS * 4);
+    dim3 g2((int)(per < 64 ? per : 64), B * C);
     if (relu) hipLaunchKernelGGL(gn_bwd_apply<true>, g2, block, 0, st, x, mean_rstd, gamma, y, gy, chan, gx, C, S);
     else hipLaunchKernelGGL(gn_bwd_apply<false>, g2, block, 0, st, x, mean_rstd, gamma, y, gy, chan, gx, C, S);
     return ECM_LAUNCH_RESULT();

@@ -356,7 +356,12 @@ class Conv3dK3(torch.autograd.Function):
     def forward(ctx, x, w, stride):
         _chk(x, w)
         x, w = _c(x), _c(w)
-        y = _conv_fwd(x, _pack_conv(w), w.shape[0], stride)
+        if _is_c1(w, stride):
+            B, Ci, D, H, W = x.shape
+            y = torch.empty(B, 1, D, H, W, device=x.device, dtype=x.dtype)
+            _lib.call("ecm_conv3d_c1_fwd", _p(x), _p(w), _p(y), B, Ci, D, H, W, _stream())
+        else:
+            y = _conv_fwd(x, _pack_conv(w), w.shape[0], stride)
         ctx.save_for_backward(x, w)
         ctx.stride = stride
         return y
@@ -373,8 +378,21 @@ class Conv3dK3(torch.autograd.Function):
             else:
                 gx = _deconv_fwd(gy, _pack_deconv(w), Ci, x.shape[2:])
         if ctx.needs_input_grad[1]:
-            gw = _wgrad(x, gy, Co, Ci, ctx.stride)
+            if _is_c1(w, ctx.stride):
+                B, _, D, H, W = x.shape
+                gw = torch.empty_like(w)
+                nb = _lib.query("ecm_conv3d_c1_wgrad_scratch_bytes", B, Ci, D, H, W)
+                scratch = _scratch(nb, x.device)
+                _lib.call("ecm_conv3d_c1_wgrad", _p(x), _p(gy), _p(gw), _p(scratch), C.c_longlong(nb), B, Ci, D, H, W,
+                          _stream())
+            else:
+                gw = _wgrad(x, gy, Co, Ci, ctx.stride)
         return gx, gw, None
+
+
+def _is_c1(w, stride):
+    """The classifier's 32 -> 1 layer has its own kernels (conv3d_c1.hip)."""
+    return w.shape[0] == 1 and stride == 1 and w.shape[1] <= 32 and w.shape[1] % 8 == 0
 
 
 def _dgrad_small_co(gy, w):

@@ -123,6 +123,13 @@ int ecm_conv3d_pack_weight(const float* w, float* packed, int Co, int Ci, int fl
 int ecm_conv3d_k3_fwd(const float* x, const float* wpacked, float* y,
                       int B, int Ci, int Co, int D, int H, int W, int stride, void* stream);
 
+/* The classifier's last layer Conv3d(Ci<=32 -> 1) (cmfsm.py:624,629,634) on its own kernels: w is the reference weight
+ * [1,Ci,3,3,3] (no packing); y: [B,1,D,H,W].  wgrad: gw [1,Ci,27] from x [B,Ci,D,H,W] and gy [B,1,D,H,W]. */
+int ecm_conv3d_c1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, void* stream);
+long long ecm_conv3d_c1_wgrad_scratch_bytes(int B, int Ci, int D, int H, int W);
+int ecm_conv3d_c1_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
+                        int B, int Ci, int D, int H, int W, void* stream);
+
 /* ConvTranspose3d k=3, stride 2, pad 1, output_padding 1 (cmfsm.py:262-281): x [B,Ci,D,H,W] -> y [B,Co,Do,Ho,Wo],
  * Do = 2D (or 2D-1 when used as the data gradient of a stride-2 conv over an odd extent).
  * Weight in the reference layout [Ci,Co,3,3,3]; a Conv3d weight [Co_f,Ci_f,27] is the same memory layout

@@ -64,6 +64,15 @@ def main():
         pk = ops._pack_conv(wt)
         od = [(d - 1) // st + 1 for d in dims]
         gf = 2.0 * 27 * ci * co * od[0] * od[1] * od[2] * B / 1e9
+        if co == 1:
+            report(f"conv3d {label} {ci}->{co} s{st} {dims}", timeit(lambda: ops.conv3d_k3(x, wt, st)), gflop=gf,
+                   gbytes=(x.numel() + x.numel() // ci) * 4 / 1e6)
+            gyc = torch.randn(B, 1, *dims, device=dev)
+            xg = x.clone().requires_grad_(False)
+            report(f"wgrad  {label} {ci}->{co}", timeit(lambda: ops.Conv3dK3.backward(
+                type("c", (), {"saved_tensors": (xg, wt), "stride": 1, "needs_input_grad": (False, True, False)}), gyc)),
+                gbytes=(x.numel() + x.numel() // ci) * 4 / 1e6)
+            continue
         report(f"conv3d {label} {ci}->{co} s{st} {dims}", timeit(lambda: ops._conv_fwd(x, pk, co, st)), gflop=gf)
     for (ci, co, dims, label) in [(64, 64, (12, 36, 60), "hg.conv5"), (64, 32, (24, 72, 120), "hg.conv6")]:
         x = torch.randn(B, ci, *dims, device=dev)

@@ -247,10 +247,19 @@ extern "C" int ecm_conv3d_k3_fwd(const float* x, const float* wpacked, float* y,
     if (Ci % 4 != 0 || Co < 1 || Co > 64 || (stride != 1 && stride != 2)) return ECM_EUNSUP;
     hipStream_t st = ecm_stream(stream);
     const bool two = Co > 32;
+    // Small volumes (the 1/8- and 1/16-resolution levels of the hourglass) would give only a few dozen workgroups with
+    // the large tile; a 1 x 4 x 32 tile trades operand reuse for enough workgroups to cover the 256 CUs.
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long long big_blocks = (long long)B * ((Do + 1) / 2) * ((Ho + 7) / 8) * ((Wo + TW - 1) / TW);
+    const bool small = big_blocks < 384;
     if (stride == 1) {
-        if (!two) return launch_conv<1, 1, 4, 8, 4>(x, wpacked, y, B, Ci, Co, D, H, W, st);
-        return launch_conv<2, 1, 2, 8, 4>(x, wpacked, y, B, Ci, Co, D, H, W, st);
+        if (!two) return small ? launch_conv<1, 1, 1, 4, 4>(x, wpacked, y, B, Ci, Co, D, H, W, st)
+                               : launch_conv<1, 1, 4, 8, 4>(x, wpacked, y, B, Ci, Co, D, H, W, st);
+        return small ? launch_conv<2, 1, 1, 4, 4>(x, wpacked, y, B, Ci, Co, D, H, W, st)
+                     : launch_conv<2, 1, 2, 8, 4>(x, wpacked, y, B, Ci, Co, D, H, W, st);
     }
-    if (!two) return launch_conv<1, 2, 2, 8, 2>(x, wpacked, y, B, Ci, Co, D, H, W, st);
-    return launch_conv<2, 2, 2, 8, 2>(x, wpacked, y, B, Ci, Co, D, H, W, st);
+    if (!two) return small ? launch_conv<1, 2, 1, 4, 2>(x, wpacked, y, B, Ci, Co, D, H, W, st)
+                           : launch_conv<1, 2, 2, 8, 2>(x, wpacked, y, B, Ci, Co, D, H, W, st);
+    return small ? launch_conv<2, 2, 1, 4, 2>(x, wpacked, y, B, Ci, Co, D, H, W, st)
+                 : launch_conv<2, 2, 2, 8, 2>(x, wpacked, y, B, Ci, Co, D, H, W, st);
 }

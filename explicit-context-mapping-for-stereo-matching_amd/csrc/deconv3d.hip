@@ -5,8 +5,8 @@
 // output o=2m+1 uses tap k=2 of input m and tap k=0 of input m+1.  Each class is a dense small
 // convolution over the INPUT grid, run as an implicit GEMM on the fp32 matrix cores exactly like
 // conv3d.hip (A = weights [co][k], B = 32 consecutive input-x voxels of one row, D = [co][voxel]).
-// One workgroup = one class x one (TD x TH x 32) tile of m; 27 taps in total over the 8 classes, so
-// the MFMA count equals that of a stride-1 conv on the input grid.
+// One workgroup = one (1 x 4 x 32) tile of input voxels for ALL 8 classes (27 taps in total), so the MFMA count equals
+// that of a stride-1 conv on the input grid and the halo tile is staged once.
 #include "common.h"
 
 namespace {
@@ -14,73 +14,67 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TW = 32;
 
-template <int CO_TILES, int TD, int TH, int CIC>
+// One workgroup = one (1 x 4 x 32) tile of INPUT voxels and ALL 8 output parity classes: the input halo tile is staged
+// once per channel chunk and every one of the 27 taps issues exactly one MFMA per k-step into the accumulator of the
+// class it belongs to (so the MFMA count equals a stride-1 conv on the input grid and no class is staging-bound).
+// Waves: 4 input rows x CO_TILES output-channel tiles (256 or 512 threads); 8 classes x 16 accumulator registers each.
+template <int CO_TILES, int CIC>
 struct DeconvCfg {
+    static constexpr int TD = 1, TH = 4;
     static constexpr int ID = TD + 1, IH = TH + 1, IW = TW + 1;
     static constexpr int RS = IW;
-    static constexpr int NT = TD * TH / 4;
     static constexpr int COP = CO_TILES * 32;
+    static constexpr int THREADS = 256 * CO_TILES;
     static constexpr int XS_FLOATS = CIC * ID * IH * RS;
-    static constexpr int WS_FLOATS = 8 * CIC * COP;                 // one parity class uses at most 8 taps
+    static constexpr int WS_FLOATS = 27 * CIC * COP;
     static constexpr int LDS_BYTES = (XS_FLOATS + 2 * WS_FLOATS) * 4;
-    static_assert((TD * TH) % 4 == 0 && NT <= TH && TH % NT == 0, "tile/wave split");
 };
 
-template <int CO_TILES, int TD, int TH, int CIC>
-__global__ __launch_bounds__(256, 2) void deconv3d_k3s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
-                                                          float* __restrict__ y, int Ci, int Co, int D, int H, int W,
-                                                          int Do, int Ho, int Wo, int tiles_d, int tiles_h,
-                                                          int tiles_w) {
-    using Cfg = DeconvCfg<CO_TILES, TD, TH, CIC>;
-    constexpr int ID = Cfg::ID, IH = Cfg::IH, IW = Cfg::IW, RS = Cfg::RS, NT = Cfg::NT, COP = Cfg::COP;
+template <int CO_TILES, int CIC>
+__global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                     float* __restrict__ y, int Ci, int Co, int D, int H,
+                                                                     int W, int Do, int Ho, int Wo, int tiles_d, int tiles_h,
+                                                                     int tiles_w) {
+    using Cfg = DeconvCfg<CO_TILES, CIC>;
+    constexpr int TD = Cfg::TD, TH = Cfg::TH, ID = Cfg::ID, IH = Cfg::IH, IW = Cfg::IW, RS = Cfg::RS, COP = Cfg::COP,
+                  NTHR = Cfg::THREADS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;
-    float* Ws = smem + Cfg::XS_FLOATS;
+    float* Xs = smem;                        // [CIC][ID][IH][RS]
+    float* Ws = smem + Cfg::XS_FLOATS;       // 2 x [27][CIC][COP]
 
     int bid = blockIdx.x;
-    const int cls = bid & 7; bid >>= 3;          // classes of one tile are adjacent workgroups (shared input in L2)
     const int tw = bid % tiles_w; bid /= tiles_w;
     const int th = bid % tiles_h; bid /= tiles_h;
     const int td = bid % tiles_d;
     const int b = bid / tiles_d;
-    const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
     const int md0 = td * TD, mh0 = th * TH, mw0 = tw * TW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int row0 = wave * NT;
-    const int dz0 = row0 / TH, hy0 = row0 % TH;
-    const int xbase = ((half * ID + dz0) * IH + hy0) * RS + l31;
-    const int wbase = half * COP + l31;
+    const int row = wave & 3, ct = wave >> 2;                    // this wave: input row (hy) and output-channel tile
+    const int xbase = (half * ID * IH + row) * RS + l31;
+    const int wbase = half * COP + ct * 32 + l31;
 
-    f32x16 acc[NT][CO_TILES];
+    f32x16 acc[8];                                               // one per parity class (pd,ph,pw)
 #pragma unroll
-    for (int r = 0; r < NT; ++r)
+    for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int ct = 0; ct < CO_TILES; ++ct)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[r][ct][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
     const size_t HWi = (size_t)H * W, DHWi = (size_t)D * HWi;
     const float* xb = x + (size_t)b * Ci * DHWi;
-    const int nd = 1 + pd, nh = 1 + ph, nw = 1 + pw;     // taps per dimension for this class
 
-    // Staging as in conv3d.hip: halo tile through registers with buffer-descriptor loads (hardware zero fill for
-    // positions beyond the input), this class's taps only ( <= 8 of the 27) by LDS-DMA into a double buffer.
     constexpr int NPOS = ID * IH * IW;
-    constexpr int PP = (NPOS + 255) / 256;
-    constexpr int NX = CIC * PP;
-    constexpr int WSLICE = CIC * COP;                              // floats per tap per chunk
-    constexpr int NWQ = (8 * WSLICE / 4 + 255) / 256;
-    float xr[NX];
+    constexpr int PP = (NPOS + NTHR - 1) / NTHR;
+    constexpr int NWQ = (27 * CIC * COP / 4 + NTHR - 1) / NTHR;
+    float xr[CIC * PP];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int ntaps = nd * nh * nw;
     unsigned posoff[PP];
 #pragma unroll
     for (int j = 0; j < PP; ++j) {
-        const int p = tid + j * 256;
+        const int p = tid + j * NTHR;
         int t = p;
         const int xx = t % IW; t /= IW;
         const int hy = t % IH;
@@ -93,14 +87,11 @@ __global__ __launch_bounds__(256, 2) void deconv3d_k3s2_mfma(const float* __rest
     auto prefetch = [&](int c0, float* wdst) {
 #pragma unroll
         for (int i = 0; i < NWQ; ++i) {
-            const int e = tid + i * 256;
-            const int lt = e / (WSLICE / 4), r = e - lt * (WSLICE / 4);         // local tap index (a_d, a_h, a_w)
-            if (lt < ntaps) {
-                const int a_w = lt % nw, a_h = (lt / nw) % nh, a_d = lt / (nw * nh);
-                const int kd = pd ? (a_d ? 0 : 2) : 1, kh = ph ? (a_h ? 0 : 2) : 1, kw = pw ? (a_w ? 0 : 2) : 1;
-                const int tap = (kd * 3 + kh) * 3 + kw;
+            const int e = tid + i * NTHR;
+            if (e < 27 * CIC * COP / 4) {
+                const int tap = e / (CIC * COP / 4), r = e - tap * (CIC * COP / 4);
                 const float* src = wp + ((size_t)tap * Ci + c0) * COP + (size_t)r * 4;
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wdst + (wave_u * 64 + i * 256) * 4), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wdst + (wave_u * 64 + i * NTHR) * 4), 16, 0, 0);
             }
         }
 #pragma unroll
@@ -120,57 +111,44 @@ __global__ __launch_bounds__(256, 2) void deconv3d_k3s2_mfma(const float* __rest
         for (int cc = 0; cc < CIC; ++cc)
 #pragma unroll
             for (int j = 0; j < PP; ++j) {
-                const int p = tid + j * 256;
+                const int p = tid + j * NTHR;
                 if (p < NPOS) Xs[cc * NPOS + p] = xr[cc * PP + j];
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const float* Wc = Ws + buf * (8 * WSLICE);
-        if (c0 + CIC < Ci) prefetch(c0 + CIC, Ws + (buf ^ 1) * (8 * WSLICE));
-        int lt = 0;
-        for (int a_d = 0; a_d < nd; ++a_d) {
-            const int sd = a_d;                                   // input offset (+0 / +1) of this tap
-            for (int a_h = 0; a_h < nh; ++a_h) {
-                const int sh = a_h;
-                for (int a_w = 0; a_w < nw; ++a_w, ++lt) {
-                    const int sw = a_w;
-                    const float* wt = Wc + wbase + lt * WSLICE;
-                    const float* xt = Xs + xbase + (sd * IH + sh) * RS + sw;
+        const float* Wc = Ws + buf * Cfg::WS_FLOATS;
+        if (c0 + CIC < Ci) prefetch(c0 + CIC, Ws + (buf ^ 1) * Cfg::WS_FLOATS);
 #pragma unroll
-                    for (int kk = 0; kk < CIC / 2; ++kk) {
-                        float a[CO_TILES];
+        for (int tap = 0; tap < 27; ++tap) {
+            // tap k of an output of parity p reads input m + (k == 0 ? 1 : 0); k == 1 <-> even output, k in {0,2} <-> odd
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int pd = kd != 1, ph = kh != 1, pw = kw != 1;
+            const int sd = kd == 0, sh = kh == 0, sw = kw == 0;
+            const int cls = (pd * 2 + ph) * 2 + pw;
 #pragma unroll
-                        for (int ct = 0; ct < CO_TILES; ++ct) a[ct] = wt[kk * 2 * COP + ct * 32];
-#pragma unroll
-                        for (int r = 0; r < NT; ++r) {
-                            const float bv = xt[(kk * 2 * ID * IH + r) * RS];
-#pragma unroll
-                            for (int ct = 0; ct < CO_TILES; ++ct)
-                                acc[r][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct], bv, acc[r][ct], 0, 0, 0);
-                        }
-                    }
-                }
+            for (int kk = 0; kk < CIC / 2; ++kk) {
+                const float a = Wc[wbase + (tap * CIC + kk * 2) * COP];
+                const float bv = Xs[xbase + ((kk * 2 * ID + sd) * IH + sh) * RS + sw];
+                acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[cls], 0, 0, 0);
             }
         }
     }
 
     const size_t HWo = (size_t)Ho * Wo, DHWo = (size_t)Do * HWo;
     float* yb = y + (size_t)b * Co * DHWo;
-    const int mw = mw0 + l31;
-    const int ow = 2 * mw + pw;
+    const int md = md0, mh = mh0 + row, mw = mw0 + l31;
+    if (md < D && mh < H && mw < W) {
 #pragma unroll
-    for (int r = 0; r < NT; ++r) {
-        const int md = md0 + dz0, mh = mh0 + hy0 + r;
-        const int od = 2 * md + pd, oh = 2 * mh + ph;
-        if (md >= D || mh >= H || mw >= W || od >= Do || oh >= Ho || ow >= Wo) continue;
-        float* yp = yb + (size_t)od * HWo + (size_t)oh * Wo + ow;
-#pragma unroll
-        for (int ct = 0; ct < CO_TILES; ++ct)
+        for (int cls = 0; cls < 8; ++cls) {
+            const int od = 2 * md + (cls >> 2), oh = 2 * mh + ((cls >> 1) & 1), ow = 2 * mw + (cls & 1);
+            if (od >= Do || oh >= Ho || ow >= Wo) continue;
+            float* yp = yb + (size_t)od * HWo + (size_t)oh * Wo + ow;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                if (co < Co) yp[(size_t)co * DHWo] = acc[r][ct][i];
+                if (co < Co) yp[(size_t)co * DHWo] = acc[cls][i];
             }
+        }
     }
 }
 
@@ -184,14 +162,14 @@ __global__ void pack_deconv_weight(const float* __restrict__ w, float* __restric
     packed[i] = o < Bc ? w[((size_t)k * Bc + o) * 27 + tap] : 0.f;
 }
 
-template <int CO_TILES, int TD, int TH, int CIC>
+template <int CO_TILES, int CIC>
 int launch_deconv(const float* x, const float* wp, float* y, int B, int Ci, int Co, int D, int H, int W, int Do, int Ho,
                   int Wo, hipStream_t st) {
-    using Cfg = DeconvCfg<CO_TILES, TD, TH, CIC>;
-    const int tiles_d = (D + TD - 1) / TD, tiles_h = (H + TH - 1) / TH, tiles_w = (W + TW - 1) / TW;
-    const long long nblk = 8LL * B * tiles_d * tiles_h * tiles_w;
+    using Cfg = DeconvCfg<CO_TILES, CIC>;
+    const int tiles_d = (D + Cfg::TD - 1) / Cfg::TD, tiles_h = (H + Cfg::TH - 1) / Cfg::TH, tiles_w = (W + TW - 1) / TW;
+    const long long nblk = (long long)B * tiles_d * tiles_h * tiles_w;
     if (nblk > 0x7fffffffLL || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
-    auto kern = deconv3d_k3s2_mfma<CO_TILES, TD, TH, CIC>;
+    auto kern = deconv3d_k3s2_mfma<CO_TILES, CIC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -199,8 +177,8 @@ int launch_deconv(const float* x, const float* wp, float* y, int B, int Ci, int 
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, x, wp, y, Ci, Co, D, H, W, Do, Ho, Wo,
-                       tiles_d, tiles_h, tiles_w);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, x, wp, y, Ci, Co, D, H, W, Do, Ho,
+                       Wo, tiles_d, tiles_h, tiles_w);
     return ECM_LAUNCH_RESULT();
 }
 
@@ -222,6 +200,6 @@ extern "C" int ecm_deconv3d_k3s2_fwd(const float* x, const float* wpacked, float
     if (Ci % 4 != 0 || Co < 1 || Co > 64) return ECM_EUNSUP;
     if (Do > 2 * D || Do < 2 * D - 1 || Ho > 2 * H || Ho < 2 * H - 1 || Wo > 2 * W || Wo < 2 * W - 1) return ECM_EUNSUP;
     hipStream_t st = ecm_stream(stream);
-    if (Co > 32) return launch_deconv<2, 2, 8, 4>(x, wpacked, y, B, Ci, Co, D, H, W, Do, Ho, Wo, st);
-    return launch_deconv<1, 4, 8, 4>(x, wpacked, y, B, Ci, Co, D, H, W, Do, Ho, Wo, st);
+    if (Co > 32) return launch_deconv<2, 4>(x, wpacked, y, B, Ci, Co, D, H, W, Do, Ho, Wo, st);
+    return launch_deconv<1, 4>(x, wpacked, y, B, Ci, Co, D, H, W, Do, Ho, Wo, st);
 }

@@ -18,4 +18,9 @@ def step():
 step(); step(); torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=45, max_shapes_column_width=70))
+rows = [e for e in prof.key_averages() if e.device_type.name != "CPU"] if hasattr(prof.key_averages()[0], "device_type") else prof.key_averages()
+rows = sorted(rows, key=lambda e: -e.self_device_time_total)
+tot = sum(e.self_device_time_total for e in rows)
+print("total device ms", tot / 1e3)
+for e in rows[:70]:
+    print(f"{e.self_device_time_total / 1e3:9.2f} ms  {100 * e.self_device_time_total / tot:5.1f}%  x{e.count:4d}  {e.key[:110]}")

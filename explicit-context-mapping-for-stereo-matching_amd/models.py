@@ -54,11 +54,38 @@ class HipReLU(nn.ReLU):
 
 
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
-    """2-D conv + GroupNorm of the encoder (cmfsm.py:36-46); stays on PyTorch-ROCm."""
+    """2-D conv + GroupNorm of the encoder (cmfsm.py:36-46).  The convolution stays on PyTorch-ROCm (MIOpen); the
+    GroupNorm (and the ReLU / residual add that follows it) runs on the same fused HIP kernel as the 3-D stack."""
     return nn.Sequential(
         nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
                   padding=dilation if dilation > 1 else pad, dilation=dilation, bias=False),
-        nn.GroupNorm(NUM_GROUPS, out_planes))
+        HipGroupNorm(NUM_GROUPS, out_planes))
+
+
+def _is_convbn(m):
+    return isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[1], HipGroupNorm)
+
+
+def _seq_fused(seq, x):
+    """Run an encoder nn.Sequential, folding every `GroupNorm -> ReLU` pair into one fused kernel launch."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+        if _is_convbn(m):
+            x = m[1].fused(m[0](x), None, relu)
+            i += 2 if relu else 1
+        elif isinstance(m, HipGroupNorm):
+            x = m.fused(x, None, relu)
+            i += 2 if relu else 1
+        elif isinstance(m, nn.Sequential):
+            x = _seq_fused(m, x)
+            i += 1
+        else:
+            x = m(x)
+            i += 1
+    return x
 
 
 def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
@@ -89,10 +116,10 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.conv2(self.conv1(x))
+        out = _seq_fused(self.conv1, x)                                    # conv + GN + ReLU
         if self.downsample is not None:
-            x = self.downsample(x)
-        return out + x
+            x = _seq_fused(self.downsample, x)
+        return self.conv2[1].fused(self.conv2[0](out), x, False)            # conv + GN + residual add (cmfsm.py:76-85)
 
 
 _INTERP_CACHE = {}
@@ -156,7 +183,7 @@ class feature_extraction(nn.Module):
         if cfg["first_tail"] == "conv":
             self.firstconv = nn.Sequential(*head, nn.Conv2d(32, 32, kernel_size=3, padding=1, stride=1, bias=False))
             self.secondconv = nn.Sequential(
-                nn.GroupNorm(NUM_GROUPS, 32), nn.ReLU(inplace=True),
+                HipGroupNorm(NUM_GROUPS, 32), nn.ReLU(inplace=True),
                 convbn(32, 32, 3, 2, 1, 1), nn.ReLU(inplace=True),
                 convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True))
         else:
@@ -183,15 +210,15 @@ class feature_extraction(nn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(
                 nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                nn.GroupNorm(NUM_GROUPS, planes * block.expansion))
+                HipGroupNorm(NUM_GROUPS, planes * block.expansion))
         layers = [block(self.inplanes, planes, stride, downsample, pad, dilation)]
         self.inplanes = planes * block.expansion
         layers += [block(self.inplanes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        output_all = self.firstconv(x)
-        output_rt = self.layer1(self.secondconv(output_all))
+        output_all = _seq_fused(self.firstconv, x)
+        output_rt = self.layer1(_seq_fused(self.secondconv, output_all))
         output_raw = self.layer2(output_rt)
         if self._raw_is_layer3:                       # cmfsm_sub_16.py:205-207
             output_raw = self.layer3(output_raw)
@@ -199,9 +226,9 @@ class feature_extraction(nn.Module):
         else:
             output_skip = self.layer4(self.layer3(output_raw))
         size = output_skip.shape[-2:]
-        pyramid = [bilinear_upsample(getattr(self, f"branch{i}")(output_skip), size) for i in (4, 3, 2, 1)]
+        pyramid = [bilinear_upsample(_seq_fused(getattr(self, f"branch{i}"), output_skip), size) for i in (4, 3, 2, 1)]
         last = self.lastconv_16 if self._raw_is_layer3 else self.lastconv
-        feature = last(torch.cat([output_raw, output_skip] + pyramid, 1))
+        feature = _seq_fused(last, torch.cat([output_raw, output_skip] + pyramid, 1))
         return feature, output_rt, output_all
 
 

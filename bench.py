@@ -158,6 +158,17 @@ def main():
         cv_bytes = (2 * 32 * Dl * h * w + 2 * 32 * h * w) * 4.0 * B
         cv_gbs = cv_bytes / (cv_ms * 1e-3) / 1e9 if cv else 0.0
         pairs = B * world * args.steps
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs,
+        # gfx950 corrections applied as profiles/r01_pmc_traffic.json says), measured at B=1 and scaled by B.
+        traffic_cv = traffic_conv = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            if (H, W, D) == (576, 960, 192):
+                traffic_cv = pm["costvol_fwd_v4"]["hbm_bytes_per_launch_B1"] * B
+                traffic_conv = pm["conv3d_k3_mfma<1,1,4,8,4> 32->32"]["hbm_bytes_per_launch_B1"] * B
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "stereo-pairs/sec (cmfsm train step fwd+bwd+Adam)" if args.mode == "train"
                       else "stereo-pairs/sec (cmfsm eval forward)",
@@ -170,12 +181,14 @@ def main():
             "ms_per_cost_volume": cv_ms / B,
             "roofline": {"kernel": "conv3d_k3_mfma<1,1,4,8,4> (all stride-1, Co<=32 launches: fwd + dgrad)", "bound": "mfma",
                          "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": None, "launches_timed": len(sel),
+                         "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_conv,
+                         "traffic_note": "HBM bytes of one 32->32 launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                         "launches_timed": len(sel),
                          "avg_launch_ms": conv_ms,
                          "of_which_32to32": {"achieved": main_tf, "frac": main_tf / PEAK_F32_MFMA_TFLOPS,
                                              "avg_launch_ms": main_ms, "launches_timed": len(main)}},
             "roofline_costvol": {"kernel": "costvol_fwd_v4", "bound": "hbm", "achieved": cv_gbs, "peak": PEAK_HBM_GBS,
-                                 "unit": "GB/s", "frac": cv_gbs / PEAK_HBM_GBS, "traffic": None,
+                                 "unit": "GB/s", "frac": cv_gbs / PEAK_HBM_GBS, "traffic": traffic_cv,
                                  "launches_timed": len(cv), "avg_launch_ms": cv_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

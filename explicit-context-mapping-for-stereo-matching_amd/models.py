@@ -370,9 +370,11 @@ class cmfsm(nn.Module):
         return preds[0].unsqueeze(1), preds[1].unsqueeze(1), preds[2].unsqueeze(1)
 
     def forward(self, left, right):
-        lr_l, _, hr_l = self.feature_extraction(left)                                  # :657
-        lr_r, _, _ = self.feature_extraction(right)                                    # :658
-        return self.hot_path(lr_l, hr_l, lr_r)
+        # cmfsm.py:657-658 runs the shared encoder twice; both images go through it as ONE batch here (GroupNorm has no
+        # cross-sample statistics, so the result is identical) -- half the launches, better-filled small layers.
+        B = left.shape[0]
+        lr, _, hr = self.feature_extraction(torch.cat([left, right], 0))
+        return self.hot_path(lr[:B], hr[:B], lr[B:])
 
 
 class similarity_measure2(nn.Module):
@@ -478,9 +480,9 @@ class _ECMNet(nn.Module):
         return tuple(preds)
 
     def forward(self, left, right):
-        lr_l, _, hr_l = self.feature_extraction(left)
-        lr_r, _, hr_r = self.feature_extraction(right)
-        return self.hot_path(lr_l, hr_l, lr_r, hr_r, out_hw=left.shape[-2:])
+        B = left.shape[0]
+        lr, _, hr = self.feature_extraction(torch.cat([left, right], 0))      # one encoder pass for both images
+        return self.hot_path(lr[:B], hr[:B], lr[B:], hr[B:], out_hw=left.shape[-2:])
 
 
 class cmfsm_sub_8(_ECMNet):

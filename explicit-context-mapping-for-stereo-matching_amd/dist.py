@@ -73,10 +73,15 @@ class FlatBucketDDP:
 
 
 def masked_smooth_l1_x3(preds, gt, maxdisp: int = 192):
-    """The reference's training loss (train.py:162,168-174): mask 0<d<maxdisp, weights 0.5/0.7/1.0."""
+    """The reference's training loss (train.py:162,168-174): mask 0<d<maxdisp, smooth-L1 'mean' over the masked pixels
+    of each head, weights 0.5/0.7/1.0.  Written without boolean-mask indexing: `o[mask]` makes ATen count the selected
+    elements on the host (a device->host sync per head and per operand, six per step); the masked mean is the same
+    number as sum(where(mask, loss, 0)) / count."""
     import torch.nn.functional as F
     mask = (gt < maxdisp) & (gt > 0)
-    o1, o2, o3 = (p.squeeze(1) for p in preds)
-    return (0.5 * F.smooth_l1_loss(o1[mask], gt[mask], reduction="mean")
-            + 0.7 * F.smooth_l1_loss(o2[mask], gt[mask], reduction="mean")
-            + F.smooth_l1_loss(o3[mask], gt[mask], reduction="mean"))
+    cnt = mask.sum().clamp_(min=1).to(gt.dtype)
+    total = 0.0
+    for wgt, p in zip((0.5, 0.7, 1.0), preds):
+        per = F.smooth_l1_loss(p.squeeze(1), gt, reduction="none")
+        total = total + wgt * (torch.where(mask, per, torch.zeros_like(per)).sum() / cnt)
+    return total

@@ -12,6 +12,13 @@
 // second kernel sums the partials in a fixed order (deterministic, no float atomics).
 #include "common.h"
 
+#ifdef WG_PROFILE
+__device__ unsigned long long wg_prof[4 * 8];     // [wave][phase] cycles of workgroup (0,0); debugging aid only
+#define WG_T(i) do { const unsigned long long now_ = clock64(); prof[i] += now_ - last; last = now_; } while (0)
+#else
+#define WG_T(i) do { } while (0)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -24,7 +31,7 @@ struct WgCfg {
     static constexpr int ID = (TD - 1) * STRIDE + 3, IH = (TH - 1) * STRIDE + 3, IW = (TWV - 1) * STRIDE + 3;
     static constexpr int RS = IW;
     static constexpr int XCH = ID * IH * RS;
-    static constexpr int XSTR = (XCH % 2 == 0) ? XCH + 1 : XCH;     // odd => 32 lanes (ci) hit 32 banks
+    static constexpr int XSTR = (XCH % 2 == 0) ? XCH + 1 : XCH + 2; // odd => 32 lanes (ci) hit 32 banks; slot XCH is a pad
     static constexpr int NV = TD * TH * TWV;
     static constexpr int GSTR = NV + 1;                              // odd
     static constexpr int LDS_FLOATS = CT * XSTR + CT * GSTR;
@@ -33,33 +40,42 @@ struct WgCfg {
 
 
 // One staged tile: TD*TH*TWV/2 k-steps (two x-adjacent voxels each), taps [T0, T0+7) of this wave.
-// The LDS operands of k-step i+1 are read before the MFMAs of k-step i are issued (explicit register double
-// buffer), so with one wave per SIMD the ~100-cycle ds_read latency hides under 7 x 64 cycles of matrix work.
-template <int STRIDE, int TD, int TH, int T0>
-__device__ __forceinline__ void wg_tile(const float* __restrict__ ga, const float* __restrict__ xb, f32x16 (&acc)[7]) {
+// With one wave per SIMD nothing else hides LDS latency, so the operands of k-step i+1 are read while the MFMAs of
+// k-step i execute: explicit register double buffer, with a sched_barrier per k-step so that hipcc cannot sink the
+// reads back next to their use (left to itself it waits lgkmcnt(0) in front of each MFMA group).
+// The NEXT tile's global loads are spread over the k-steps too (issue(i), i < NLOADS): issued in one burst they
+// stall the wave on the 64-entry vmcnt window for ~13K cycles per tile with the matrix core idle (measured 17.6 %).
+template <int STRIDE, int TD, int TH, int T0, int NLOADS, class Issue>
+__device__ __forceinline__ void wg_tile(const float* __restrict__ ga, const float* __restrict__ xb, f32x16 (&acc)[7],
+                                        Issue&& issue) {
     using Cfg = WgCfg<STRIDE, TD, TH>;
     constexpr int IH = Cfg::IH, RS = Cfg::RS;
     constexpr int NT = (T0 + 7 <= 27) ? 7 : 27 - T0;          // taps of this wave (the last wave has 6)
     constexpr int KS = TD * TH * TWV / 2;
-    auto a_off = [](int ks) constexpr { return ks * 2; };     // voxel index of the pair: (dz*TH+hy)*TWV + xx == 2*ks
+    constexpr int KSI = KS * 3 / 4;                           // all issued within the first 3/4 of the k-steps, so that
+    constexpr int LPK = (NLOADS + KSI - 1) / KSI;             // their latency is not exposed at the LDS stores that follow
     auto b_off = [](int ks, int t) constexpr {
         const int xx = (ks * 2) % TWV, hy = ((ks * 2) / TWV) % TH, dz = (ks * 2) / (TWV * TH);
         const int tap = T0 + t, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         return ((dz * STRIDE + kd) * IH + hy * STRIDE + kh) * RS + xx * STRIDE + kw;
     };
-    float a_cur = ga[a_off(0)], b_cur[NT];
+    float a_cur = ga[0], b_cur[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) b_cur[t] = xb[b_off(0, t)];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         float a_nxt = 0.f, b_nxt[NT];
         if (ks + 1 < KS) {
-            a_nxt = ga[a_off(ks + 1)];
+            a_nxt = ga[(ks + 1) * 2];                          // voxel index of the pair == 2*ks
 #pragma unroll
             for (int t = 0; t < NT; ++t) b_nxt[t] = xb[b_off(ks + 1, t)];
         }
 #pragma unroll
+        for (int q = 0; q < LPK; ++q)
+            if (ks * LPK + q < NLOADS) issue(ks * LPK + q);
+#pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);     // nothing moves across k-steps: next step's reads stay ahead of these MFMAs
         a_cur = a_nxt;
 #pragma unroll
         for (int t = 0; t < NT; ++t) b_cur[t] = b_nxt[t];
@@ -90,84 +106,111 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_mfma(const float* __restr
 
     const size_t HWi = (size_t)H * W, DHWi = (size_t)D * HWi;
     const size_t HWo = (size_t)Ho * Wo, DHWo = (size_t)Do * HWo;
-    const long long ntiles = (long long)B * tiles_d * tiles_h * tiles_w;
+    const int ntiles = B * tiles_d * tiles_h * tiles_w;       // < 2^31 (checked by the host)
 
     // Register-pipelined staging through buffer descriptors (see conv3d.hip): the loads of the NEXT tile are issued
-    // before this tile's MFMA loop; positions outside the volume carry offset 0x80000000 and read back as 0.
+    // inside this tile's MFMA loop; positions outside the volume carry offset 0x80000000 and read back as 0.
     constexpr int NPOSX = ID * IH * IW;
     constexpr int PPX = (NPOSX + 255) / 256;                 // x positions per thread per channel
     constexpr int GPL = 256 / NV;                            // gy channels covered by one 256-thread pass
     static_assert(256 % NV == 0 && CT % GPL == 0, "gy tile must divide the workgroup");
     constexpr int NGRP = CT / GPL;
+    constexpr int NLOADS = CT * PPX + NGRP;
     float xr[CT * PPX], gr[NGRP];
     const unsigned xplane = (unsigned)DHWi * 4u, gplane = (unsigned)DHWo * 4u;
-    auto prefetch = [&](long long tile) {
-        long long r = tile;
-        const int tw = (int)(r % tiles_w); r /= tiles_w;
-        const int th = (int)(r % tiles_h); r /= tiles_h;
-        const int td = (int)(r % tiles_d);
-        const int b = (int)(r / tiles_d);
+    const int nci = Ci - ci0 < CT ? Ci - ci0 : CT, nco = Co - co0 < CT ? Co - co0 : CT;
+    unsigned xoff[PPX], goff;
+    auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0, 0x00020000);
+    auto grs = xrs;
+    // Tile-invariant part of the staging map: this thread's PPX halo positions (dz,hy,xx) and their linear offset.
+    int pdz[PPX], phy[PPX], pxx[PPX], prel[PPX];
+#pragma unroll
+    for (int j = 0; j < PPX; ++j) {
+        int t = tid + j * 256;
+        pxx[j] = t % IW; t /= IW;
+        phy[j] = t % IH;
+        const bool in_tile = tid + j * 256 < NPOSX;
+        prel[j] = in_tile ? (t / IH) * (int)HWi + phy[j] * W + pxx[j] : 0;
+        pdz[j] = in_tile ? t / IH : -(1 << 20);                      // past the halo tile: never inside the volume
+    }
+    const int gv = tid % NV, gccl = tid / NV;
+    const int gxx = gv % TWV, ghy = (gv / TWV) % TH, gdz = gv / (TWV * TH);
+    const int grel = gdz * (int)HWo + ghy * Wo + gxx;
+    // Per-tile addressing of the next tile (tile >= ntiles: every offset out of range, the loads return 0 untouched).
+    auto prefetch_setup = [&](unsigned tile) {
+        const bool live = tile < (unsigned)ntiles;
+        unsigned r = live ? tile : 0u;
+        const int tw = (int)(r % (unsigned)tiles_w); r /= (unsigned)tiles_w;
+        const int th = (int)(r % (unsigned)tiles_h); r /= (unsigned)tiles_h;
+        const int td = (int)(r % (unsigned)tiles_d);
+        const int b = (int)(r / (unsigned)tiles_d);
         const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TWV;
         const int id0 = od0 * STRIDE - 1, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
-        unsigned xoff[PPX];
+        const int xbase = id0 * (int)HWi + ih0 * W + iw0;
 #pragma unroll
         for (int j = 0; j < PPX; ++j) {
-            const int p = tid + j * 256;
-            int t = p;
-            const int xx = t % IW; t /= IW;
-            const int hy = t % IH;
-            const int dz = t / IH;
-            const int gz = id0 + dz, gyy = ih0 + hy, gx = iw0 + xx;
-            const bool ok = p < NPOSX && (unsigned)gz < (unsigned)D && (unsigned)gyy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            xoff[j] = ok ? (unsigned)(gz * (int)HWi + gyy * W + gx) * 4u : 0x80000000u;
+            const bool ok = live && (unsigned)(id0 + pdz[j]) < (unsigned)D && (unsigned)(ih0 + phy[j]) < (unsigned)H &&
+                            (unsigned)(iw0 + pxx[j]) < (unsigned)W;
+            xoff[j] = ok ? (unsigned)(xbase + prel[j]) * 4u : 0x80000000u;
         }
         // ONE descriptor per tensor and sample; the (uniform) channel offset is added to the per-lane offset.  The
         // out-of-volume marker 0x80000000 stays >= num_records after adding any channel offset (< 2^31 bytes per sample).
-        const int nci = Ci - ci0 < CT ? Ci - ci0 : CT, nco = Co - co0 < CT ? Co - co0 : CT;
-        const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + ((size_t)b * Ci + ci0) * DHWi), 0,
-                                                           (unsigned)nci * xplane, 0x00020000);
-#pragma unroll
-        for (int cc = 0; cc < CT; ++cc)
-#pragma unroll
-            for (int j = 0; j < PPX; ++j)
-                xr[cc * PPX + j] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[j] + (unsigned)cc * xplane, 0, 0));
+        xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + ((size_t)b * Ci + ci0) * DHWi), 0,
+                                                (unsigned)nci * xplane, 0x00020000);
         // gy: thread -> (channel within group = tid / NV, voxel = tid % NV)
-        const int v = tid % NV, ccl = tid / NV;
-        const int xx = v % TWV, hy = (v / TWV) % TH, dz = v / (TWV * TH);
-        const int od = od0 + dz, oh = oh0 + hy, ow = ow0 + xx;
-        const bool vok = od < Do && oh < Ho && ow < Wo;
-        const unsigned goff = vok ? (unsigned)(od * (int)HWo + oh * Wo + ow) * 4u + (unsigned)ccl * gplane : 0x80000000u;
-        const auto grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy + ((size_t)b * Co + co0) * DHWo), 0,
-                                                           (unsigned)nco * gplane, 0x00020000);
-#pragma unroll
-        for (int g = 0; g < NGRP; ++g)
-            gr[g] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(grs, goff + (unsigned)(g * GPL) * gplane, 0, 0));
+        const bool vok = live && od0 + gdz < Do && oh0 + ghy < Ho && ow0 + gxx < Wo;
+        goff = vok ? (unsigned)(od0 * (int)HWo + oh0 * Wo + ow0 + grel) * 4u + (unsigned)gccl * gplane : 0x80000000u;
+        grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy + ((size_t)b * Co + co0) * DHWo), 0,
+                                                (unsigned)nco * gplane, 0x00020000);
     };
-    if ((long long)blockIdx.x < ntiles) prefetch(blockIdx.x);
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    auto prefetch_issue = [&](int i) {          // i is a compile-time constant at every (unrolled) call site
+        if (i < CT * PPX) {
+            const int cc = i / PPX, j = i % PPX;
+            xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[j] + (unsigned)cc * xplane, 0, 0));
+        } else {
+            const int g = i - CT * PPX;
+            gr[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, goff + (unsigned)(g * GPL) * gplane, 0, 0));
+        }
+    };
+#ifdef WG_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = clock64();
+#endif
+    prefetch_setup((unsigned)blockIdx.x);
+#pragma unroll
+    for (int i = 0; i < NLOADS; ++i) prefetch_issue(i);
+    WG_T(0);
+    for (unsigned tile = blockIdx.x; tile < (unsigned)ntiles; tile += gridDim.x) {
         __syncthreads();
+        WG_T(1);
+        // Unconditional stores (positions past the halo tile land in the per-channel pad slot): a guarded store costs
+        // a saveexec/branch pair each, and there are CT*PPX of them on the critical path between two MFMA loops.
 #pragma unroll
-        for (int cc = 0; cc < CT; ++cc)
+        for (int j = 0; j < PPX; ++j) {
+            const int p = tid + j * 256 < NPOSX ? tid + j * 256 : NPOSX;
 #pragma unroll
-            for (int j = 0; j < PPX; ++j) {
-                const int p = tid + j * 256;
-                if (p < NPOSX) Xs[cc * XSTR + p] = xr[cc * PPX + j];       // [ci][dz][hy][xx], odd channel stride
-            }
+            for (int cc = 0; cc < CT; ++cc) Xs[cc * XSTR + p] = xr[cc * PPX + j];   // [ci][dz][hy][xx], odd channel stride
+        }
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) Gs[(g * GPL + tid / NV) * GSTR + tid % NV] = gr[g];
+        WG_T(2);
         __syncthreads();
-        if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        WG_T(3);
+        prefetch_setup(tile + gridDim.x);
+        WG_T(4);
         const float* ga = Gs + l31 * GSTR + half;
         const float* xb = Xs + l31 * XSTR + half * STRIDE;
         switch (wave) {          // wave-uniform: makes every tap offset a compile-time immediate
-            case 0: wg_tile<STRIDE, TD, TH, 0>(ga, xb, acc); break;
-            case 1: wg_tile<STRIDE, TD, TH, 7>(ga, xb, acc); break;
-            case 2: wg_tile<STRIDE, TD, TH, 14>(ga, xb, acc); break;
-            default: wg_tile<STRIDE, TD, TH, 21>(ga, xb, acc); break;
+            case 0: wg_tile<STRIDE, TD, TH, 0, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            case 1: wg_tile<STRIDE, TD, TH, 7, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            case 2: wg_tile<STRIDE, TD, TH, 14, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            default: wg_tile<STRIDE, TD, TH, 21, NLOADS>(ga, xb, acc, prefetch_issue); break;
         }
+        WG_T(5);
     }
+#ifdef WG_PROFILE
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) wg_prof[wave * 8 + i] = prof[i];
+#endif
     // ---- write this workgroup's partial: partial[blockIdx.x][co][ci][tap] ------------------------------
     float* pp = partial + (size_t)blockIdx.x * Co * Ci * 27;
 #pragma unroll
@@ -241,6 +284,7 @@ extern "C" int ecm_conv3d_k3_wgrad(const float* x, const float* gy, float* gw, v
     ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0);
     if (stride != 1 && stride != 2) return ECM_EUNSUP;
     if ((long long)D * H * W * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;  // 32-bit buffer offsets over a 32-channel tile
+    if (ntiles_for(B, D, H, W, stride) >= 0x7fffffffLL) return ECM_EUNSUP;   // 32-bit tile counter
     if (scratch_bytes < ecm_conv3d_wgrad_scratch_bytes(B, Ci, Co, D, H, W, stride)) return ECM_ESCRATCH;
     float* partial = static_cast<float*>(scratch);
     hipStream_t st = ecm_stream(stream);

@@ -1,0 +1,33 @@
+// Phase-level cycle profile of the wgrad kernel (workgroup 0): build with
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DWG_PROFILE -Iinclude -Iexplicit-context-mapping-for-stereo-matching_amd/csrc tools/micro/wgrad_prof.hip -o tools/micro/wgrad_prof
+#include "conv3d_wgrad.hip"
+#include <cstdio>
+#include <vector>
+int main(int argc, char** argv) {
+    const int stride = argc > 1 ? atoi(argv[1]) : 1;
+    const int B = 1, Ci = 32, Co = 32, D = 48, H = 144, W = 240;
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const size_t nx = (size_t)B * Ci * D * H * W, ng = (size_t)B * Co * Do * Ho * Wo;
+    float *x, *g, *gw; void* scratch;
+    hipMalloc(&x, nx * 4); hipMalloc(&g, ng * 4); hipMalloc(&gw, (size_t)Co * Ci * 27 * 4);
+    hipMemset(x, 0, nx * 4); hipMemset(g, 0, ng * 4);
+    const long long sb = ecm_conv3d_wgrad_scratch_bytes(B, Ci, Co, D, H, W, stride);
+    hipMalloc(&scratch, sb);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 3; ++r) {
+        hipEventRecord(e0);
+        int rc = ecm_conv3d_k3_wgrad(x, g, gw, scratch, sb, B, Ci, Co, D, H, W, stride, nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("rc=%d  %.3f ms\n", rc, ms);
+    }
+    unsigned long long prof[32];
+    hipMemcpyFromSymbol(prof, HIP_SYMBOL(wg_prof), sizeof(prof));
+    const char* names[6] = {"first prefetch", "barrier A (wait others)", "LDS stores (+vmcnt)", "barrier B", "prefetch issue", "MFMA loop"};
+    for (int w = 0; w < 4; ++w) {
+        unsigned long long tot = 0; for (int i = 0; i < 6; ++i) tot += prof[w * 8 + i];
+        printf("wave %d total %llu cycles\n", w, tot);
+        for (int i = 0; i < 6; ++i) printf("   %-26s %10llu  %5.1f%%\n", names[i], prof[w * 8 + i], 100.0 * prof[w * 8 + i] / tot);
+    }
+    return 0;
+}

@@ -48,7 +48,8 @@ PROTOTYPES = {
     "ecm_gn3d_scratch_bytes": (_LL, [_I, _I, _LL]),
     "ecm_gn3d_stats": (_I, [_P, _P, _P, _LL, _I, _I, _LL, _F, _P]),
     "ecm_gn3d_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _LL, _I, _P]),
-    "ecm_gn3d_bwd": (_I, [_P] * 10 + [_LL, _I, _I, _LL, _I, _P]),
+    "ecm_gn3d_fwd": (_I, [_P] * 7 + [_LL, _I, _I, _LL, _I, _F, _P]),
+    "ecm_gn3d_bwd": (_I, [_P] * 11 + [_LL, _I, _I, _LL, _I, _P]),
 }
 
 _lib = None

@@ -15,6 +15,13 @@
 // feeds CO_TILES MFMAs; every LDS offset inside the chunk loop is a compile-time immediate.
 #include "common.h"
 
+#ifdef CV_PROFILE
+__device__ unsigned long long cv_prof[4 * 8];     // [wave][phase] cycles of workgroup 0; debugging aid only
+#define CV_T(i) do { const unsigned long long now_ = clock64(); prof[i] += now_ - last; last = now_; } while (0)
+#else
+#define CV_T(i) do { } while (0)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -59,6 +66,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
+#ifdef CV_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = clock64();
+#endif
     // this wave's first row -> (dz0, hy0); later rows are compile-time offsets from it
     const int row0 = wave * NT;
     const int dz0 = (NT <= TH) ? row0 / TH : (row0 / TH);
@@ -127,9 +137,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
         }
     };
     prefetch(0, Ws);
+    CV_T(0);
     int buf = 0;
     for (int c0 = 0; c0 < Ci; c0 += CIC, buf ^= 1) {
         __syncthreads();                                   // previous chunk's LDS reads are done
+        CV_T(1);
 #pragma unroll
         for (int cc = 0; cc < CIC; ++cc)
 #pragma unroll
@@ -138,9 +150,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
                 if (p < NPOS) Xs[cc * NPOS + p] = xr[cc * PP + j];          // [cc][dz][hy][xx], RS == IW
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight DMA for this chunk has landed
+        CV_T(2);
         __syncthreads();
+        CV_T(3);
         const float* Wc = Ws + buf * Cfg::WS_FLOATS;
         if (c0 + CIC < Ci) prefetch(c0 + CIC, Ws + (buf ^ 1) * Cfg::WS_FLOATS);   // in flight during the MFMA loop below
+        CV_T(4);
         // ---- 27 * CIC/2 k-steps ---------------------------------------------------------------
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
@@ -162,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
                 }
             }
         }
+        CV_T(5);
     }
 
     // ---- epilogue: D[co][voxel] -> y[b,co,od,oh,ow] ---------------------------------------------
@@ -183,6 +199,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
                 if (co < Co) yp[(size_t)co * DHWo] = acc[r][ct][i];
             }
     }
+#ifdef CV_PROFILE
+    CV_T(6);
+    if (blockIdx.x == 2000 && lane == 0)
+        for (int i = 0; i < 8; ++i) cv_prof[wave * 8 + i] = prof[i];
+#endif
 }
 
 // Conv3d weight [Co,Ci,27] -> [27][Ci][COP] (zero padded co), or the dgrad operator:

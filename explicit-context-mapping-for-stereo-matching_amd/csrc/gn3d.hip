@@ -26,6 +26,13 @@ __device__ __forceinline__ void block_reduce2(float& a, float& b, float* sm) {
     b = sm[1];
 }
 
+// y = fma(x, a, sh): the coefficients are formed the same way wherever they are needed, so that the ReLU mask
+// recomputed in the backward pass is bit-identical to the forward decision.
+__device__ __forceinline__ void gn_affine(float mean, float rstd, float gamma, float beta, float& a, float& sh) {
+    a = rstd * gamma;
+    sh = __builtin_fmaf(-mean, a, beta);
+}
+
 // stage 1: partial (sum, sumsq) of chunk `blockIdx.x` of span `blockIdx.y` (= b*32+g); span = n contiguous floats
 __global__ __launch_bounds__(THREADS) void gn_stats_partial(const float* __restrict__ x, float* __restrict__ part,
                                                             long long n, int nchunks) {
@@ -74,13 +81,15 @@ __global__ __launch_bounds__(THREADS) void gn_apply(const float* __restrict__ x,
     const int b = bc / C, c = bc - b * C;
     const int g = c / (C / GROUPS);
     const float mean = mean_rstd[(b * GROUPS + g) * 2], rstd = mean_rstd[(b * GROUPS + g) * 2 + 1];
-    const float a = rstd * gamma[c], sh = beta[c] - mean * a;
+    float a, sh;
+    gn_affine(mean, rstd, gamma[c], beta[c], a, sh);
     const size_t base = (size_t)bc * S;
     const long long stride = (long long)gridDim.x * THREADS * 4;
     if ((S & 3) == 0) {
         for (long long i = ((long long)blockIdx.x * THREADS + threadIdx.x) * 4; i < S; i += stride) {
             float4 v = *reinterpret_cast<const float4*>(x + base + i);
-            v.x = v.x * a + sh; v.y = v.y * a + sh; v.z = v.z * a + sh; v.w = v.w * a + sh;
+            v.x = __builtin_fmaf(v.x, a, sh); v.y = __builtin_fmaf(v.y, a, sh);
+            v.z = __builtin_fmaf(v.z, a, sh); v.w = __builtin_fmaf(v.w, a, sh);
             if (SKIP) {
                 const float4 k = *reinterpret_cast<const float4*>(skip + base + i);
                 v.x += k.x; v.y += k.y; v.z += k.z; v.w += k.w;
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(THREADS) void gn_apply(const float* __restrict__ x,
         }
     } else {
         for (long long i = (long long)blockIdx.x * THREADS + threadIdx.x; i < S; i += (long long)gridDim.x * THREADS) {
-            float v = x[base + i] * a + sh;
+            float v = __builtin_fmaf(x[base + i], a, sh);
             if (SKIP) v += skip[base + i];
             if (RELU) v = fmaxf(v, 0.f);
             y[base + i] = v;
@@ -101,8 +110,9 @@ __global__ __launch_bounds__(THREADS) void gn_apply(const float* __restrict__ x,
 // ---- backward -------------------------------------------------------------------------------
 // stage 1: per (b,c) chunk partials of  sg = sum g,  sgx = sum g*xhat   with g = gy * [y>0] (relu) ; also writes
 // gskip = g when requested.  grid: (nchunks, B*C)
-template <bool RELU>
+template <int MASK>
 __global__ __launch_bounds__(THREADS) void gn_bwd_partial(const float* __restrict__ x, const float* __restrict__ mean_rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ y, const float* __restrict__ gy,
                                                           float* __restrict__ gskip, float* __restrict__ part, int C,
                                                           long long S, int nchunks) {
@@ -114,19 +124,27 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_partial(const float* __restric
     const size_t base = (size_t)bc * S;
     const long long beg = (long long)blockIdx.x * CHUNK;
     const long long end = beg + CHUNK < S ? beg + CHUNK : S;
+    float a = 0.f, sh = 0.f;
+    if (MASK == 2) gn_affine(mean, rstd, gamma[c], beta[c], a, sh);
     float sg = 0.f, sgx = 0.f;
     if ((S & 3) == 0) {
         for (long long i = beg + threadIdx.x * 4; i < end; i += THREADS * 4) {
             float4 gv = *reinterpret_cast<const float4*>(gy + base + i);
-            if (RELU) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+            if (MASK == 1) {
                 const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
                 if (!(yv.x > 0.f)) gv.x = 0.f;
                 if (!(yv.y > 0.f)) gv.y = 0.f;
                 if (!(yv.z > 0.f)) gv.z = 0.f;
                 if (!(yv.w > 0.f)) gv.w = 0.f;
             }
+            if (MASK == 2) {
+                if (!(__builtin_fmaf(xv.x, a, sh) > 0.f)) gv.x = 0.f;
+                if (!(__builtin_fmaf(xv.y, a, sh) > 0.f)) gv.y = 0.f;
+                if (!(__builtin_fmaf(xv.z, a, sh) > 0.f)) gv.z = 0.f;
+                if (!(__builtin_fmaf(xv.w, a, sh) > 0.f)) gv.w = 0.f;
+            }
             if (gskip) *reinterpret_cast<float4*>(gskip + base + i) = gv;
-            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
             sg += (gv.x + gv.y) + (gv.z + gv.w);
             sgx += (gv.x * ((xv.x - mean) * rstd) + gv.y * ((xv.y - mean) * rstd)) +
                    (gv.z * ((xv.z - mean) * rstd) + gv.w * ((xv.w - mean) * rstd));
@@ -134,7 +152,8 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_partial(const float* __restric
     } else {
         for (long long i = beg + threadIdx.x; i < end; i += THREADS) {
             float gv = gy[base + i];
-            if (RELU && !(y[base + i] > 0.f)) gv = 0.f;
+            if (MASK == 1 && !(y[base + i] > 0.f)) gv = 0.f;
+            if (MASK == 2 && !(__builtin_fmaf(x[base + i], a, sh) > 0.f)) gv = 0.f;
             if (gskip) gskip[base + i] = gv;
             sg += gv;
             sgx += gv * ((x[base + i] - mean) * rstd);
@@ -169,11 +188,12 @@ __global__ void gn_bwd_params(const float* __restrict__ chan, float* __restrict_
 }
 
 // gx = rstd * (g*gamma - s1/n - xhat*s2/n),  s1 = sum_{c in group} gamma_c sg_c,  s2 = sum gamma_c sgx_c
-template <bool RELU>
+template <int MASK>
 __global__ __launch_bounds__(THREADS) void gn_bwd_apply(const float* __restrict__ x, const float* __restrict__ mean_rstd,
-                                                        const float* __restrict__ gamma, const float* __restrict__ y,
-                                                        const float* __restrict__ gy, const float* __restrict__ chan,
-                                                        float* __restrict__ gx, int C, long long S) {
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ y, const float* __restrict__ gy,
+                                                        const float* __restrict__ chan, float* __restrict__ gx, int C,
+                                                        long long S) {
     const int bc = blockIdx.y;
     const int b = bc / C, c = bc - b * C;
     const int cpg = C / GROUPS, g = c / cpg;
@@ -186,18 +206,26 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_apply(const float* __restrict_
     }
     const float invn = 1.f / ((float)cpg * (float)S);
     const float gm = gamma[c], k1 = s1 * invn, k2 = s2 * invn;
+    float a = 0.f, sh = 0.f;
+    if (MASK == 2) gn_affine(mean, rstd, gm, beta[c], a, sh);
     const size_t base = (size_t)bc * S;
     if ((S & 3) == 0) {
         for (long long i = ((long long)blockIdx.x * THREADS + threadIdx.x) * 4; i < S; i += (long long)gridDim.x * THREADS * 4) {
             float4 gv = *reinterpret_cast<const float4*>(gy + base + i);
-            if (RELU) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+            if (MASK == 1) {
                 const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
                 if (!(yv.x > 0.f)) gv.x = 0.f;
                 if (!(yv.y > 0.f)) gv.y = 0.f;
                 if (!(yv.z > 0.f)) gv.z = 0.f;
                 if (!(yv.w > 0.f)) gv.w = 0.f;
             }
-            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+            if (MASK == 2) {
+                if (!(__builtin_fmaf(xv.x, a, sh) > 0.f)) gv.x = 0.f;
+                if (!(__builtin_fmaf(xv.y, a, sh) > 0.f)) gv.y = 0.f;
+                if (!(__builtin_fmaf(xv.z, a, sh) > 0.f)) gv.z = 0.f;
+                if (!(__builtin_fmaf(xv.w, a, sh) > 0.f)) gv.w = 0.f;
+            }
             float4 o;
             o.x = rstd * (gv.x * gm - k1 - ((xv.x - mean) * rstd) * k2);
             o.y = rstd * (gv.y * gm - k1 - ((xv.y - mean) * rstd) * k2);
@@ -208,12 +236,284 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_apply(const float* __restrict_
     } else {
         for (long long i = (long long)blockIdx.x * THREADS + threadIdx.x; i < S; i += (long long)gridDim.x * THREADS) {
             float gv = gy[base + i];
-            if (RELU && !(y[base + i] > 0.f)) gv = 0.f;
+            if (MASK == 1 && !(y[base + i] > 0.f)) gv = 0.f;
+            if (MASK == 2 && !(__builtin_fmaf(x[base + i], a, sh) > 0.f)) gv = 0.f;
             const float xh = (x[base + i] - mean) * rstd;
             gx[base + i] = rstd * (gv * gm - k1 - xh * k2);
         }
     }
 }
+
+// ---- cluster-fused kernels -------------------------------------------------------------------
+// The two-stage kernels above read every tensor once for the statistics and again for the elementwise pass (forward:
+// 2 reads + 1 write; backward with ReLU: 6 reads + 1 write).  The fused kernels keep a workgroup's slice of the span
+// in REGISTERS across the reduction: a cluster of `cl` co-resident workgroups owns one (sample, group) span, each
+// workgroup loads its slice once (<= MAXV4 float4 per thread), publishes a partial sum into its slot, collects the
+// cl slots of the span (agent-scope atomics), reduces them in a fixed order and finishes from registers
+// (forward: 1 read + 1 write; backward: 2 reads + 1 write, the ReLU mask is recomputed from x when no skip was added).
+// The grid never exceeds what is resident at once (occupancy query), so the collect cannot deadlock; a bounded
+// spin turns a lost workgroup into NaN statistics instead of a hang.  Shapes that do not fit (S % 4, spans larger
+// than the register capacity of 256 workgroups) take the two-stage path.
+constexpr int FUSED_MAX_CL = 256;
+constexpr int FUSED_MAX_CPG = 8;
+#ifndef ECM_GN_FWD_MAXV4
+#define ECM_GN_FWD_MAXV4 32       // measured on MI355X (tools/gn_bench.py, B=4 x 32 x 48x144x240): 32@2 / 20@2 -> fwd 0.344 ms,
+#define ECM_GN_FWD_OCC 2          // bwd 0.544 ms; 16@4 / 8@4 -> 0.417 / 0.594; 24@3 / 12@3 -> 0.368 / 0.589 (two-stage fwd 0.517)
+#define ECM_GN_BWD_MAXV4 20
+#define ECM_GN_BWD_OCC 2
+#endif
+constexpr int FWD_MAXV4 = ECM_GN_FWD_MAXV4;   // float4 per thread kept in registers; OCC workgroups per CU overlap one
+constexpr int BWD_MAXV4 = ECM_GN_BWD_MAXV4;   // cluster's wait with another's loads/stores
+
+// Slice access through buffer descriptors (base = first float4 of this workgroup's slice, num_records = slice bytes):
+// one 32-bit per-thread offset + immediates instead of a 64-bit address per register tile row, and float4s past the
+// slice read as 0 / are not written, so the tile loops carry no bounds predicate.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const float* p, int nv4) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, nv4 > 0 ? nv4 * 16 : 0, 0x00020000);
+}
+__device__ __forceinline__ float4 slice_ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void slice_st(__amdgpu_buffer_rsrc_t r, unsigned off, const float4& f) {
+    u32x4 v;
+    v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Cluster exchange without fences: a workgroup's partial (two floats) is published as ONE 64-bit agent-scope atomic
+// store into a slot preset to EMPTY, and read back with agent-scope atomic loads, so data and "ready" flag travel
+// together and no release/acquire (= whole-L2 write-back / invalidate on a multi-XCD part) is needed.
+constexpr unsigned long long SLOT_EMPTY = ~0ull;          // (NaN, NaN) with an all-ones payload: never produced by sums
+
+__device__ __forceinline__ void slot_publish(unsigned long long* slot, float s, float q) {
+    const unsigned long long v = ((unsigned long long)__float_as_uint(q) << 32) | (unsigned long long)__float_as_uint(s);
+    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Poll until the slot is filled (bounded: a workgroup that never ran turns into NaN results, not a hang).
+__device__ __forceinline__ bool slot_collect(const unsigned long long* slot, float& s, float& q) {
+    unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (v == SLOT_EMPTY) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 23)) break;
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s = __uint_as_float((unsigned)(v & 0xffffffffull));
+    q = __uint_as_float((unsigned)(v >> 32));
+    return v != SLOT_EMPTY;
+}
+
+struct FusedGeom {
+    int cpg, wpc, cl, nclusters, nspans;
+    long long v4_per_wg;
+    bool ok;
+};
+
+inline FusedGeom fused_geom(int B, int C, long long S, int maxv4, int resident) {
+    FusedGeom g{};
+    g.ok = false;
+    if (S % 4 != 0 || S / 4 >= 0x7fffffffLL - 0x10000 || C % GROUPS != 0 || resident <= 0) return g;
+    g.cpg = C / GROUPS;
+    if (g.cpg > FUSED_MAX_CPG) return g;
+    const long long nv4 = S / 4, cap = (long long)THREADS * maxv4;
+    const long long wpc = (nv4 + cap - 1) / cap;
+    if (wpc * g.cpg > FUSED_MAX_CL || wpc * g.cpg > resident) return g;
+    g.wpc = (int)wpc;
+    g.cl = g.wpc * g.cpg;
+    g.nspans = B * GROUPS;
+    g.nclusters = resident / g.cl < g.nspans ? resident / g.cl : g.nspans;
+    g.v4_per_wg = (nv4 + wpc - 1) / wpc;
+    g.ok = true;
+    return g;
+}
+
+template <class K>
+inline int resident_workgroups(K kern) {
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, THREADS, 0) != hipSuccess) return 0;
+    return cus * per;
+}
+
+// scratch layout of the fused path: slots [nspans][cl] x 64 bit (preset to SLOT_EMPTY by the launcher)
+template <bool RELU, bool SKIP>
+__global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ skip,
+                                                           float* __restrict__ y, float* __restrict__ mean_rstd,
+                                                           unsigned long long* slots, int C, long long S, int cpg,
+                                                           int wpc, int nclusters, int nspans, long long v4_per_wg,
+                                                           float eps) {
+    constexpr int MAXV4 = FWD_MAXV4;
+    __shared__ float sm[2 * THREADS / 64];
+    __shared__ double smd[2 * THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = cpg * wpc;
+    const int cluster = blockIdx.x / cl, wic = blockIdx.x - cluster * cl;
+    const int cig = wic / wpc, w = wic - cig * wpc;
+    const long long nv4 = S >> 2;                       // < 2^31 (checked by the host): 32-bit indices within a channel
+    const int v0 = (int)((long long)w * v4_per_wg);
+    const int v1 = (int)(v0 + v4_per_wg < nv4 ? v0 + v4_per_wg : nv4);
+    const unsigned toff = (unsigned)(wave * MAXV4 * 64 + lane) * 16u;     // wave-contiguous rows of 64 float4 (1 KB)
+    for (int span = cluster; span < nspans; span += nclusters) {
+        const int b = span / GROUPS, g = span - b * GROUPS;
+        const int c = g * cpg + cig;
+        const size_t base = ((size_t)b * C + c) * S;
+        const auto xr = slice_rsrc(x + base + (size_t)v0 * 4, v1 - v0);
+        float4 v[MAXV4];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV4; ++j) {
+            v[j] = slice_ld(xr, toff + j * 1024);
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+        }
+        block_reduce2(s, q, sm);
+        unsigned long long* sp = slots + (size_t)span * cl;
+        if (tid == 0) slot_publish(sp + wic, s, q);
+        // fixed-order total of the cl (<= 256) partials, identical in every workgroup of the cluster
+        double ds = 0.0, dq = 0.0;
+        int got = 1;
+        if (tid < cl) { float ps, pq; got = slot_collect(sp + tid, ps, pq) ? 1 : 0; ds = (double)ps; dq = (double)pq; }
+        const bool arrived = __syncthreads_and(got) != 0;
+        ds = wave_sum_d(ds); dq = wave_sum_d(dq);
+        if (lane == 0) { smd[wave * 2] = ds; smd[wave * 2 + 1] = dq; }
+        __syncthreads();
+        ds = (smd[0] + smd[2]) + (smd[4] + smd[6]);
+        dq = (smd[1] + smd[3]) + (smd[5] + smd[7]);
+        const double n = (double)cpg * (double)S;
+        const double dmean = ds / n;
+        double var = dq / n - dmean * dmean;
+        if (var < 0.0) var = 0.0;
+        float mean = (float)dmean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (!arrived) mean = rstd = __builtin_nanf("");
+        if (wic == 0 && tid == 0) { mean_rstd[span * 2] = mean; mean_rstd[span * 2 + 1] = rstd; }
+        float a, sh;
+        gn_affine(mean, rstd, gamma[c], beta[c], a, sh);
+        const auto yr = slice_rsrc(y + base + (size_t)v0 * 4, v1 - v0);
+        const auto kr = slice_rsrc(SKIP ? skip + base + (size_t)v0 * 4 : x, SKIP ? v1 - v0 : 0);
+#pragma unroll
+        for (int j = 0; j < MAXV4; ++j) {
+            float4 o = v[j];
+            o.x = __builtin_fmaf(o.x, a, sh); o.y = __builtin_fmaf(o.y, a, sh);
+            o.z = __builtin_fmaf(o.z, a, sh); o.w = __builtin_fmaf(o.w, a, sh);
+            if (SKIP) { const float4 k = slice_ld(kr, toff + j * 1024); o.x += k.x; o.y += k.y; o.z += k.z; o.w += k.w; }
+            if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            slice_st(yr, toff + j * 1024, o);
+        }
+        __syncthreads();          // smd / sm are reused by the next span
+    }
+}
+
+// MASK: 0 = no ReLU, 1 = mask from the forward output y, 2 = mask recomputed as fma(x, a, sh) > 0 (forward without skip)
+template <int MASK, bool GSKIP>
+__global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const float* __restrict__ x, const float* __restrict__ mean_rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ y, const float* __restrict__ gy,
+                                                           float* __restrict__ gx, float* __restrict__ gskip,
+                                                           float* __restrict__ chan, unsigned long long* slots, int C,
+                                                           long long S, int cpg, int wpc, int nclusters, int nspans,
+                                                           long long v4_per_wg) {
+    constexpr int MAXV4 = BWD_MAXV4;
+    __shared__ float sm[2 * THREADS / 64];
+    __shared__ double chs[2 * FUSED_MAX_CPG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = cpg * wpc;
+    const int cluster = blockIdx.x / cl, wic = blockIdx.x - cluster * cl;
+    const int cig = wic / wpc, w = wic - cig * wpc;
+    const long long nv4 = S >> 2;                       // < 2^31 (checked by the host): 32-bit indices within a channel
+    const int v0 = (int)((long long)w * v4_per_wg);
+    const int v1 = (int)(v0 + v4_per_wg < nv4 ? v0 + v4_per_wg : nv4);
+    const unsigned toff = (unsigned)(wave * MAXV4 * 64 + lane) * 16u;     // wave-contiguous rows of 64 float4 (1 KB)
+    for (int span = cluster; span < nspans; span += nclusters) {
+        const int b = span / GROUPS, g = span - b * GROUPS;
+        const int c = g * cpg + cig;
+        const size_t base = ((size_t)b * C + c) * S;
+        const float mean = mean_rstd[span * 2], rstd = mean_rstd[span * 2 + 1];
+        const float gm = gamma[c];
+        float a = 0.f, sh = 0.f;
+        if (MASK == 2) gn_affine(mean, rstd, gm, beta[c], a, sh);
+        const auto xr = slice_rsrc(x + base + (size_t)v0 * 4, v1 - v0);
+        const auto gr = slice_rsrc(gy + base + (size_t)v0 * 4, v1 - v0);
+        const auto yr = slice_rsrc(MASK == 1 ? y + base + (size_t)v0 * 4 : x, MASK == 1 ? v1 - v0 : 0);
+        const auto kr = slice_rsrc(GSKIP ? gskip + base + (size_t)v0 * 4 : x, GSKIP ? v1 - v0 : 0);
+        float4 xv[MAXV4], gv[MAXV4];
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV4; ++j) {
+            float4 xx = slice_ld(xr, toff + j * 1024), gg = slice_ld(gr, toff + j * 1024);
+            if (MASK == 1) {
+                const float4 yv = slice_ld(yr, toff + j * 1024);
+                if (!(yv.x > 0.f)) gg.x = 0.f;
+                if (!(yv.y > 0.f)) gg.y = 0.f;
+                if (!(yv.z > 0.f)) gg.z = 0.f;
+                if (!(yv.w > 0.f)) gg.w = 0.f;
+            }
+            if (MASK == 2) {
+                if (!(__builtin_fmaf(xx.x, a, sh) > 0.f)) gg.x = 0.f;
+                if (!(__builtin_fmaf(xx.y, a, sh) > 0.f)) gg.y = 0.f;
+                if (!(__builtin_fmaf(xx.z, a, sh) > 0.f)) gg.z = 0.f;
+                if (!(__builtin_fmaf(xx.w, a, sh) > 0.f)) gg.w = 0.f;
+            }
+            if (GSKIP) slice_st(kr, toff + j * 1024, gg);
+            // keep xhat (x itself is not needed again).  Past the slice x reads 0 => xhat = -mean*rstd, but g = 0 there.
+            xx.x = (xx.x - mean) * rstd; xx.y = (xx.y - mean) * rstd;
+            xx.z = (xx.z - mean) * rstd; xx.w = (xx.w - mean) * rstd;
+            sg += (gg.x + gg.y) + (gg.z + gg.w);
+            sgx += (gg.x * xx.x + gg.y * xx.y) + (gg.z * xx.z + gg.w * xx.w);
+            xv[j] = xx; gv[j] = gg;
+        }
+        block_reduce2(sg, sgx, sm);
+        unsigned long long* sp = slots + (size_t)span * cl;
+        if (tid == 0) slot_publish(sp + wic, sg, sgx);
+        // per-channel totals (fixed order): wave k reduces the wpc partials of channels k, k+4, ...
+        int got = 1;
+        for (int cc = wave; cc < cpg; cc += THREADS / 64) {
+            double ds = 0.0, dq = 0.0;
+            for (int i = lane; i < wpc; i += 64) {
+                float ps, pq;
+                if (!slot_collect(sp + cc * wpc + i, ps, pq)) got = 0;
+                ds += (double)ps; dq += (double)pq;
+            }
+            ds = wave_sum_d(ds); dq = wave_sum_d(dq);
+            if (lane == 0) { chs[cc * 2] = ds; chs[cc * 2 + 1] = dq; }
+        }
+        const bool arrived = __syncthreads_and(got) != 0;
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < cpg; ++j) {
+            const float gj = gamma[g * cpg + j];
+            s1 += gj * (float)chs[j * 2];
+            s2 += gj * (float)chs[j * 2 + 1];
+        }
+        if (w == 0 && tid == 0) {
+            chan[((size_t)b * C + c) * 2] = arrived ? (float)chs[cig * 2] : __builtin_nanf("");
+            chan[((size_t)b * C + c) * 2 + 1] = (float)chs[cig * 2 + 1];
+        }
+        const float invn = 1.f / ((float)cpg * (float)S);
+        const float k1 = arrived ? s1 * invn : __builtin_nanf(""), k2 = s2 * invn;
+        const auto orr = slice_rsrc(gx + base + (size_t)v0 * 4, v1 - v0);
+#pragma unroll
+        for (int j = 0; j < MAXV4; ++j) {
+            float4 o;
+            o.x = rstd * (gv[j].x * gm - k1 - xv[j].x * k2);
+            o.y = rstd * (gv[j].y * gm - k1 - xv[j].y * k2);
+            o.z = rstd * (gv[j].z * gm - k1 - xv[j].z * k2);
+            o.w = rstd * (gv[j].w * gm - k1 - xv[j].w * k2);
+            slice_st(orr, toff + j * 1024, o);
+        }
+        __syncthreads();          // chs / sm are reused by the next span
+    }
+}
+
+inline long long fused_scratch_floats(int B) { return (long long)B * GROUPS * FUSED_MAX_CL * 2; }   // 64-bit slots
 
 inline int chunks_of(long long n) { return (int)((n + CHUNK - 1) / CHUNK); }
 
@@ -224,7 +524,9 @@ extern "C" long long ecm_gn3d_scratch_bytes(int B, int C, long long S) {
     const long long cpg = C / 32 > 0 ? C / 32 : 1;
     const long long a = (long long)B * 32 * chunks_of(cpg * S) * 2;
     const long long b = (long long)B * C * chunks_of(S) * 2 + (long long)B * C * 2;
-    return (a > b ? a : b) * (long long)sizeof(float);
+    const long long f = fused_scratch_floats(B) + (long long)B * C * 2;          // cluster partials + counters, chan
+    const long long m = a > b ? a : b;
+    return (m > f ? m : f) * (long long)sizeof(float);
 }
 
 extern "C" int ecm_gn3d_stats(const float* x, float* mean_rstd, void* scratch, long long scratch_bytes, int B, int C,
@@ -257,25 +559,101 @@ extern "C" int ecm_gn3d_apply(const float* x, const float* mean_rstd, const floa
     return ECM_LAUNCH_RESULT();
 }
 
-extern "C" int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* y, const float* gy,
-                            float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch, long long scratch_bytes,
-                            int B, int C, long long S, int relu, void* stream) {
-    ECM_CHECK_ARG(x && mean_rstd && gamma && gy && gx && ggamma && gbeta && scratch && B > 0 && C > 0 && S > 0);
-    ECM_CHECK_ARG(!relu || y);
+namespace {
+
+// Launch helpers of the fused kernels; -100 = the shape needs the two-stage path.
+template <bool RELU, bool SKIP>
+int launch_fused_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, float* mean_rstd,
+                     float* scratch, int B, int C, long long S, float eps, hipStream_t st) {
+    auto kern = gn_fused_fwd<RELU, SKIP>;
+    static int resident = -1;
+    if (resident < 0) resident = resident_workgroups(kern);
+    const FusedGeom g = fused_geom(B, C, S, FWD_MAXV4, resident);
+    if (!g.ok) return -100;
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(scratch);
+    hipError_t e = hipMemsetAsync(slots, 0xff, (size_t)g.nspans * g.cl * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(g.nclusters * g.cl), dim3(THREADS), 0, st, x, gamma, beta, skip, y, mean_rstd, slots, C,
+                       S, g.cpg, g.wpc, g.nclusters, g.nspans, g.v4_per_wg, eps);
+    return ECM_LAUNCH_RESULT();
+}
+
+template <int MASK, bool GSKIP>
+int launch_fused_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
+                     const float* gy, float* gx, float* gskip, float* chan, float* scratch, int B, int C, long long S,
+                     hipStream_t st) {
+    auto kern = gn_fused_bwd<MASK, GSKIP>;
+    static int resident = -1;
+    if (resident < 0) resident = resident_workgroups(kern);
+    const FusedGeom g = fused_geom(B, C, S, BWD_MAXV4, resident);
+    if (!g.ok) return -100;
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(scratch);
+    hipError_t e = hipMemsetAsync(slots, 0xff, (size_t)g.nspans * g.cl * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(g.nclusters * g.cl), dim3(THREADS), 0, st, x, mean_rstd, gamma, beta, y, gy, gx, gskip,
+                       chan, slots, C, S, g.cpg, g.wpc, g.nclusters, g.nspans, g.v4_per_wg);
+    return ECM_LAUNCH_RESULT();
+}
+
+}  // namespace
+
+extern "C" int ecm_gn3d_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y,
+                            float* mean_rstd, void* scratch, long long scratch_bytes, int B, int C, long long S,
+                            int relu, float eps, void* stream) {
+    ECM_CHECK_ARG(x && gamma && beta && y && mean_rstd && scratch && B > 0 && C > 0 && S > 0);
     if (C % GROUPS != 0 || (long long)B * C > 65535) return ECM_EUNSUP;
     if (scratch_bytes < ecm_gn3d_scratch_bytes(B, C, S)) return ECM_ESCRATCH;
-    const int nchunks = chunks_of(S);
-    float* part = static_cast<float*>(scratch);
-    float* chan = part + (size_t)B * C * nchunks * 2;
     hipStream_t st = ecm_stream(stream);
+    float* sc = static_cast<float*>(scratch);
+    int rc;
+    if (relu && skip) rc = launch_fused_fwd<true, true>(x, gamma, beta, skip, y, mean_rstd, sc, B, C, S, eps, st);
+    else if (relu) rc = launch_fused_fwd<true, false>(x, gamma, beta, skip, y, mean_rstd, sc, B, C, S, eps, st);
+    else if (skip) rc = launch_fused_fwd<false, true>(x, gamma, beta, skip, y, mean_rstd, sc, B, C, S, eps, st);
+    else rc = launch_fused_fwd<false, false>(x, gamma, beta, skip, y, mean_rstd, sc, B, C, S, eps, st);
+    if (rc != -100) return rc;
+    rc = ecm_gn3d_stats(x, mean_rstd, scratch, scratch_bytes, B, C, S, eps, stream);
+    if (rc) return rc;
+    return ecm_gn3d_apply(x, mean_rstd, gamma, beta, skip, y, B, C, S, relu, stream);
+}
+
+extern "C" int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
+                            const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
+                            long long scratch_bytes, int B, int C, long long S, int relu, void* stream) {
+    ECM_CHECK_ARG(x && mean_rstd && gamma && gy && gx && ggamma && gbeta && scratch && B > 0 && C > 0 && S > 0);
+    ECM_CHECK_ARG(!relu || y || beta);          // the ReLU mask comes from y, or is recomputed from x with beta
+    if (C % GROUPS != 0 || (long long)B * C > 65535) return ECM_EUNSUP;
+    if (scratch_bytes < ecm_gn3d_scratch_bytes(B, C, S)) return ECM_ESCRATCH;
+    const int mask = !relu ? 0 : (y ? 1 : 2);
+    hipStream_t st = ecm_stream(stream);
+    float* sc = static_cast<float*>(scratch);
+    {   // fused: chan lives behind the cluster slots
+        float* chan = sc + fused_scratch_floats(B);
+        int rc;
+        if (mask == 0) rc = gskip ? launch_fused_bwd<0, true>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
+                                  : launch_fused_bwd<0, false>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
+        else if (mask == 1) rc = gskip ? launch_fused_bwd<1, true>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
+                                       : launch_fused_bwd<1, false>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
+        else rc = gskip ? launch_fused_bwd<2, true>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
+                        : launch_fused_bwd<2, false>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
+        if (rc == 0) {
+            hipLaunchKernelGGL(gn_bwd_params, dim3((C + 63) / 64), dim3(64), 0, st, chan, ggamma, gbeta, B, C);
+            return ECM_LAUNCH_RESULT();
+        }
+        if (rc != -100) return rc;
+    }
+    const int nchunks = chunks_of(S);
+    float* part = sc;
+    float* chan = part + (size_t)B * C * nchunks * 2;
     dim3 g1(nchunks, B * C), block(THREADS);
-    if (relu) hipLaunchKernelGGL(gn_bwd_partial<true>, g1, block, 0, st, x, mean_rstd, y, gy, gskip, part, C, S, nchunks);
-    else hipLaunchKernelGGL(gn_bwd_partial<false>, g1, block, 0, st, x, mean_rstd, y, gy, gskip, part, C, S, nchunks);
+    if (mask == 0) hipLaunchKernelGGL(gn_bwd_partial<0>, g1, block, 0, st, x, mean_rstd, gamma, beta, y, gy, gskip, part, C, S, nchunks);
+    else if (mask == 1) hipLaunchKernelGGL(gn_bwd_partial<1>, g1, block, 0, st, x, mean_rstd, gamma, beta, y, gy, gskip, part, C, S, nchunks);
+    else hipLaunchKernelGGL(gn_bwd_partial<2>, g1, block, 0, st, x, mean_rstd, gamma, beta, y, gy, gskip, part, C, S, nchunks);
     hipLaunchKernelGGL(gn_bwd_final_chan, dim3((B * C + 63) / 64), dim3(64), 0, st, part, chan, B * C, nchunks);
     hipLaunchKernelGGL(gn_bwd_params, dim3((C + 63) / 64), dim3(64), 0, st, chan, ggamma, gbeta, B, C);
     long long per = (S + THREADS * 4 - 1) / (THREADS * 4);
     dim3 g2((int)(per < 64 ? per : 64), B * C);
-    if (relu) hipLaunchKernelGGL(gn_bwd_apply<true>, g2, block, 0, st, x, mean_rstd, gamma, y, gy, chan, gx, C, S);
-    else hipLaunchKernelGGL(gn_bwd_apply<false>, g2, block, 0, st, x, mean_rstd, gamma, y, gy, chan, gx, C, S);
+    if (mask == 0) hipLaunchKernelGGL(gn_bwd_apply<0>, g2, block, 0, st, x, mean_rstd, gamma, beta, y, gy, chan, gx, C, S);
+    else if (mask == 1) hipLaunchKernelGGL(gn_bwd_apply<1>, g2, block, 0, st, x, mean_rstd, gamma, beta, y, gy, chan, gx, C, S);
+    else hipLaunchKernelGGL(gn_bwd_apply<2>, g2, block, 0, st, x, mean_rstd, gamma, beta, y, gy, chan, gx, C, S);
     return ECM_LAUNCH_RESULT();
 }

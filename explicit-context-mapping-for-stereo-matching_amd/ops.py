@@ -455,18 +455,17 @@ class GroupNormAct(torch.autograd.Function):
         stats = torch.empty(B, GN_GROUPS, 2, device=x.device, dtype=x.dtype)
         nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
         scratch = _scratch(nb, x.device)
-        _lib.call("ecm_gn3d_stats", _p(x), _p(stats), _p(scratch), C.c_longlong(nb), B, Cc, C.c_longlong(S),
-                  C.c_float(GN_EPS), _stream())
         y = torch.empty_like(x)
-        _lib.call("ecm_gn3d_apply", _p(x), _p(stats), _p(gamma), _p(beta), _p(skip), _p(y), B, Cc, C.c_longlong(S),
-                  int(relu), _stream())
-        ctx.save_for_backward(x, stats, gamma, y if relu else None)
+        _lib.call("ecm_gn3d_fwd", _p(x), _p(gamma), _p(beta), _p(skip), _p(y), _p(stats), _p(scratch), C.c_longlong(nb),
+                  B, Cc, C.c_longlong(S), int(relu), C.c_float(GN_EPS), _stream())
+        # ReLU mask in backward: recomputed from x unless a skip was added (then the output y is needed)
+        ctx.save_for_backward(x, stats, gamma, beta, y if (relu and skip is not None) else None)
         ctx.relu, ctx.has_skip = relu, skip is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, stats, gamma, y = ctx.saved_tensors
+        x, stats, gamma, beta, y = ctx.saved_tensors
         gy = _c(gy)
         B, Cc = x.shape[:2]
         S = x.numel() // (B * Cc)
@@ -478,7 +477,7 @@ class GroupNormAct(torch.autograd.Function):
         gbeta = torch.zeros_like(gamma)
         nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
         scratch = _scratch(nb, x.device)
-        _lib.call("ecm_gn3d_bwd", _p(x), _p(stats), _p(gamma), _p(y), _p(gy), _p(gx),
+        _lib.call("ecm_gn3d_bwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(gy), _p(gx),
                   _p(gskip if (ctx.has_skip and ctx.relu) else None), _p(ggamma), _p(gbeta), _p(scratch),
                   C.c_longlong(nb), B, Cc, C.c_longlong(S), int(ctx.relu), _stream())
         return gx, ggamma, gbeta, gskip, None

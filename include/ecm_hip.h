@@ -144,19 +144,25 @@ long long ecm_conv3d_wgrad_scratch_bytes(int B, int Ci, int Co, int D, int H, in
 int ecm_conv3d_k3_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
                         int B, int Ci, int Co, int D, int H, int W, int stride, void* stream);
 
-/* GroupNorm(32 groups, eps) over [B,C,S] (S = D*H*W), cmfsm.py:58; deterministic two-stage reductions.
- * scratch for all three calls: >= ecm_gn3d_scratch_bytes(B,C,S).
- * stats: mean_rstd [B,32,2].  apply: y = relu?( (x-mean)*rstd*gamma[c]+beta[c] (+ skip) )  (skip may be NULL). */
+/* GroupNorm(32 groups, eps) over [B,C,S] (S = D*H*W), cmfsm.py:58; deterministic fixed-order reductions.
+ * scratch for every call: >= ecm_gn3d_scratch_bytes(B,C,S).
+ * fwd: y = relu?( (x-mean)*rstd*gamma[c]+beta[c] (+ skip) ) (skip may be NULL) and mean_rstd [B,32,2] in ONE pass over x
+ *      (a cluster of co-resident workgroups keeps the span in registers across the reduction); shapes that do not fit
+ *      that kernel run stats + apply.  stats / apply are also exported on their own. */
 long long ecm_gn3d_scratch_bytes(int B, int C, long long S);
+int ecm_gn3d_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y,
+                 float* mean_rstd, void* scratch, long long scratch_bytes, int B, int C, long long S,
+                 int relu, float eps, void* stream);
 int ecm_gn3d_stats(const float* x, float* mean_rstd, void* scratch, long long scratch_bytes,
                    int B, int C, long long S, float eps, void* stream);
 int ecm_gn3d_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
                    const float* skip, float* y, int B, int C, long long S, int relu, void* stream);
 /* Backward of y = relu?(gn(x) + skip): writes gx and gskip (NULL to skip it); ACCUMULATES into ggamma[C], gbeta[C].
- * y is the forward OUTPUT (relu mask; may be NULL when relu == 0). */
-int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* y, const float* gy,
-                 float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch, long long scratch_bytes,
-                 int B, int C, long long S, int relu, void* stream);
+ * ReLU mask (relu != 0): from the forward OUTPUT y when y != NULL; with y == NULL it is recomputed from x, which needs
+ * beta and is only valid for a forward WITHOUT skip (saves one tensor read per pass).  beta may be NULL otherwise. */
+int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
+                 const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
+                 long long scratch_bytes, int B, int C, long long S, int relu, void* stream);
 
 #ifdef __cplusplus
 }

@@ -170,7 +170,10 @@ def test_ecm_module_tuple(ecm, cmfsm_sd):
 # ------------------------------------------------------------------ GroupNorm
 @pytest.mark.parametrize("B,C,dims,relu,skip", [(1, 32, (4, 6, 10), True, False), (2, 64, (3, 5, 7), True, True),
                                                 (1, 32, (8, 8, 8), False, True), (2, 32, (2, 3, 5), False, False),
-                                                (1, 64, (16, 24, 40), True, True)])
+                                                (1, 64, (16, 24, 40), True, True),
+                                                # several workgroups per channel in the register-resident cluster kernels
+                                                (2, 32, (8, 48, 96), True, False), (1, 64, (8, 48, 96), True, True),
+                                                (1, 128, (1, 96, 160), False, False), (2, 32, (12, 40, 100), False, True)])
 def test_groupnorm(ecm, B, C, dims, relu, skip):
     x = seeded("gn.x", B, C, *dims) * 1.7 + 0.3
     gm, bt = 1 + 0.2 * seeded("gn.g", C), 0.2 * seeded("gn.b", C)

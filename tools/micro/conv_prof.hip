@@ -1,0 +1,31 @@
+// Phase-level cycle profile of the forward 3x3x3 conv kernel (workgroup 2000): build with
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCV_PROFILE -Iinclude -Iexplicit-context-mapping-for-stereo-matching_amd/csrc tools/micro/conv_prof.hip -o tools/micro/conv_prof
+#include "conv3d.hip"
+#include <cstdio>
+int main(int argc, char** argv) {
+    const int Ci = argc > 1 ? atoi(argv[1]) : 32, Co = argc > 2 ? atoi(argv[2]) : 32, stride = argc > 3 ? atoi(argv[3]) : 1;
+    const int B = 1, D = 48, H = 144, W = 240;
+    const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const size_t nx = (size_t)B * Ci * D * H * W, ny = (size_t)B * Co * Do * Ho * Wo;
+    float *x, *y, *wp;
+    hipMalloc(&x, nx * 4); hipMalloc(&y, ny * 4); hipMalloc(&wp, ecm_conv3d_packed_floats(Ci, Co) * 4);
+    hipMemset(x, 0, nx * 4); hipMemset(wp, 0, ecm_conv3d_packed_floats(Ci, Co) * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 3; ++r) {
+        hipEventRecord(e0);
+        int rc = ecm_conv3d_k3_fwd(x, wp, y, B, Ci, Co, D, H, W, stride, nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double fl = 2.0 * 27 * Ci * Co * (double)Do * Ho * Wo * B;
+        printf("rc=%d  %.3f ms  %.1f TFLOP/s\n", rc, ms, fl / ms / 1e9);
+    }
+    unsigned long long prof[32];
+    hipMemcpyFromSymbol(prof, HIP_SYMBOL(cv_prof), sizeof(prof));
+    const char* names[7] = {"setup + first prefetch", "barrier A", "LDS stores (+vmcnt)", "barrier B", "prefetch issue", "MFMA loop", "epilogue"};
+    for (int w = 0; w < 4; w += 3) {
+        unsigned long long tot = 0; for (int i = 0; i < 7; ++i) tot += prof[w * 8 + i];
+        printf("wave %d total %llu cycles\n", w, tot);
+        for (int i = 0; i < 7; ++i) printf("   %-26s %10llu  %5.1f%%\n", names[i], prof[w * 8 + i], 100.0 * prof[w * 8 + i] / tot);
+    }
+    return 0;
+}

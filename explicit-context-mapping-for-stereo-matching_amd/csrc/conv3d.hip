@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
     }
 #ifdef CV_PROFILE
     CV_T(6);
-    if (blockIdx.x == 2000 && lane == 0)
+    if (blockIdx.x == 700 && lane == 0)
         for (int i = 0; i < 8; ++i) cv_prof[wave * 8 + i] = prof[i];
 #endif
 }

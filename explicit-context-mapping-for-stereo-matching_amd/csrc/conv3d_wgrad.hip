@@ -26,9 +26,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CT = 32;        // channel tile (both co and ci)
 constexpr int TWV = 16;       // output voxels per tile row
 
-template <int STRIDE, int TD, int TH>
+// KD = 3: the 3x3x3 Conv3d.  KD = 1: a 3x3 Conv2d seen as a depth-1 volume with no taps and no padding along depth
+// (the encoder's convbn, cmfsm.py:37-47) -- same staging, 9 taps.
+template <int STRIDE, int TD, int TH, int KD>
 struct WgCfg {
-    static constexpr int ID = (TD - 1) * STRIDE + 3, IH = (TH - 1) * STRIDE + 3, IW = (TWV - 1) * STRIDE + 3;
+    static constexpr int NTAPS = 9 * KD, PADD = KD / 2;
+    // wave plan: KD=3 -> 4 tap groups of 7 (the last has 6), every wave runs all k-steps;
+    //            KD=1 -> 2 tap groups (5 + 4) x 2 halves of the k-steps (each half writes its own partial).
+    static constexpr int TG = KD == 3 ? 4 : 2, KG = 4 / TG, MAXNT = KD == 3 ? 7 : 5;
+    static constexpr int ID = (TD - 1) * STRIDE + KD, IH = (TH - 1) * STRIDE + 3, IW = (TWV - 1) * STRIDE + 3;
     static constexpr int RS = IW;
     static constexpr int XCH = ID * IH * RS;
     static constexpr int XSTR = (XCH % 2 == 0) ? XCH + 1 : XCH + 2; // odd => 32 lanes (ci) hit 32 banks; slot XCH is a pad
@@ -45,25 +51,27 @@ struct WgCfg {
 // reads back next to their use (left to itself it waits lgkmcnt(0) in front of each MFMA group).
 // The NEXT tile's global loads are spread over the k-steps too (issue(i), i < NLOADS): issued in one burst they
 // stall the wave on the 64-entry vmcnt window for ~13K cycles per tile with the matrix core idle (measured 17.6 %).
-template <int STRIDE, int TD, int TH, int T0, int NLOADS, class Issue>
-__device__ __forceinline__ void wg_tile(const float* __restrict__ ga, const float* __restrict__ xb, f32x16 (&acc)[7],
-                                        Issue&& issue) {
-    using Cfg = WgCfg<STRIDE, TD, TH>;
+template <int STRIDE, int TD, int TH, int KD, int TGI, int KGI, int NLOADS, class Issue>
+__device__ __forceinline__ void wg_tile(const float* __restrict__ ga, const float* __restrict__ xb,
+                                        f32x16 (&acc)[WgCfg<STRIDE, TD, TH, KD>::MAXNT], Issue&& issue) {
+    using Cfg = WgCfg<STRIDE, TD, TH, KD>;
     constexpr int IH = Cfg::IH, RS = Cfg::RS;
-    constexpr int NT = (T0 + 7 <= 27) ? 7 : 27 - T0;          // taps of this wave (the last wave has 6)
-    constexpr int KS = TD * TH * TWV / 2;
-    constexpr int KSI = KS * 3 / 4;                           // all issued within the first 3/4 of the k-steps, so that
+    constexpr int T0 = TGI * Cfg::MAXNT;                                         // this wave's taps [T0, T0+NT)
+    constexpr int NT = (T0 + Cfg::MAXNT <= Cfg::NTAPS) ? Cfg::MAXNT : Cfg::NTAPS - T0;
+    constexpr int KSA = TD * TH * TWV / 2;
+    constexpr int KS0 = KGI * (KSA / Cfg::KG), KS = KS0 + KSA / Cfg::KG;         // this wave's k-steps [KS0, KS)
+    constexpr int KSI = (KS - KS0) * 3 / 4;                   // all issued within the first 3/4 of the k-steps, so that
     constexpr int LPK = (NLOADS + KSI - 1) / KSI;             // their latency is not exposed at the LDS stores that follow
     auto b_off = [](int ks, int t) constexpr {
         const int xx = (ks * 2) % TWV, hy = ((ks * 2) / TWV) % TH, dz = (ks * 2) / (TWV * TH);
-        const int tap = T0 + t, kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        const int tap = T0 + t, kd = KD == 3 ? tap / 9 : 0, kh = (tap / 3) % 3, kw = tap % 3;
         return ((dz * STRIDE + kd) * IH + hy * STRIDE + kh) * RS + xx * STRIDE + kw;
     };
-    float a_cur = ga[0], b_cur[NT];
+    float a_cur = ga[KS0 * 2], b_cur[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) b_cur[t] = xb[b_off(0, t)];
+    for (int t = 0; t < NT; ++t) b_cur[t] = xb[b_off(KS0, t)];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = KS0; ks < KS; ++ks) {
         float a_nxt = 0.f, b_nxt[NT];
         if (ks + 1 < KS) {
             a_nxt = ga[(ks + 1) * 2];                          // voxel index of the pair == 2*ks
@@ -72,7 +80,7 @@ __device__ __forceinline__ void wg_tile(const float* __restrict__ ga, const floa
         }
 #pragma unroll
         for (int q = 0; q < LPK; ++q)
-            if (ks * LPK + q < NLOADS) issue(ks * LPK + q);
+            if ((ks - KS0) * LPK + q < NLOADS) issue((ks - KS0) * LPK + q);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);     // nothing moves across k-steps: next step's reads stay ahead of these MFMAs
@@ -82,14 +90,14 @@ __device__ __forceinline__ void wg_tile(const float* __restrict__ ga, const floa
     }
 }
 
-template <int STRIDE, int TD, int TH>
-__global__ __launch_bounds__(256, 1) void conv3d_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
+template <int STRIDE, int TD, int TH, int KD>
+__global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
                                                          float* __restrict__ partial, int B, int Ci, int Co, int D,
                                                          int H, int W, int Do, int Ho, int Wo, int tiles_d, int tiles_h,
                                                          int tiles_w, int ci_tiles) {
-    using Cfg = WgCfg<STRIDE, TD, TH>;
-    constexpr int ID = Cfg::ID, IH = Cfg::IH, IW = Cfg::IW, RS = Cfg::RS, XSTR = Cfg::XSTR, NV = Cfg::NV,
-                  GSTR = Cfg::GSTR;
+    using Cfg = WgCfg<STRIDE, TD, TH, KD>;
+    constexpr int ID = Cfg::ID, IH = Cfg::IH, IW = Cfg::IW, XSTR = Cfg::XSTR, NV = Cfg::NV, GSTR = Cfg::GSTR,
+                  NTAPS = Cfg::NTAPS, MAXNT = Cfg::MAXNT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                     // [32 ci][XSTR]
     float* Gs = smem + CT * XSTR;         // [32 co][GSTR]
@@ -97,10 +105,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_mfma(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int ci0 = (blockIdx.y % ci_tiles) * CT, co0 = (blockIdx.y / ci_tiles) * CT;
-    const int t0 = wave * 7;                                   // this wave's taps [t0, t0+nt)
-    f32x16 acc[7];
+    const int tgi = wave % Cfg::TG, kgi = wave / Cfg::TG;      // tap group, k-step group of this wave
+    const int t0 = tgi * MAXNT;                                // this wave's taps [t0, t0+nt)
+    f32x16 acc[MAXNT];
 #pragma unroll
-    for (int t = 0; t < 7; ++t)
+    for (int t = 0; t < MAXNT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_mfma(const float* __restr
         const int td = (int)(r % (unsigned)tiles_d);
         const int b = (int)(r / (unsigned)tiles_d);
         const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TWV;
-        const int id0 = od0 * STRIDE - 1, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
+        const int id0 = od0 * STRIDE - Cfg::PADD, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
         const int xbase = id0 * (int)HWi + ih0 * W + iw0;
 #pragma unroll
         for (int j = 0; j < PPX; ++j) {
@@ -200,10 +209,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_mfma(const float* __restr
         const float* ga = Gs + l31 * GSTR + half;
         const float* xb = Xs + l31 * XSTR + half * STRIDE;
         switch (wave) {          // wave-uniform: makes every tap offset a compile-time immediate
-            case 0: wg_tile<STRIDE, TD, TH, 0, NLOADS>(ga, xb, acc, prefetch_issue); break;
-            case 1: wg_tile<STRIDE, TD, TH, 7, NLOADS>(ga, xb, acc, prefetch_issue); break;
-            case 2: wg_tile<STRIDE, TD, TH, 14, NLOADS>(ga, xb, acc, prefetch_issue); break;
-            default: wg_tile<STRIDE, TD, TH, 21, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            case 0: wg_tile<STRIDE, TD, TH, KD, 0 % Cfg::TG, 0 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            case 1: wg_tile<STRIDE, TD, TH, KD, 1 % Cfg::TG, 1 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            case 2: wg_tile<STRIDE, TD, TH, KD, 2 % Cfg::TG, 2 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            default: wg_tile<STRIDE, TD, TH, KD, 3 % Cfg::TG, 3 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
         }
         WG_T(5);
     }
@@ -211,47 +220,69 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_mfma(const float* __restr
     if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
         for (int i = 0; i < 8; ++i) wg_prof[wave * 8 + i] = prof[i];
 #endif
-    // ---- write this workgroup's partial: partial[blockIdx.x][co][ci][tap] ------------------------------
-    float* pp = partial + (size_t)blockIdx.x * Co * Ci * 27;
+    // ---- write this wave's partial: partial[blockIdx.x * KG + k-group][co][ci][tap] -------------------
+    float* pp = partial + ((size_t)blockIdx.x * Cfg::KG + kgi) * Co * Ci * NTAPS;
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
+    for (int t = 0; t < MAXNT; ++t) {
         const int tap = t0 + t;
-        if (tap >= 27) continue;
+        if (tap >= NTAPS) continue;
         const int ci = ci0 + l31;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-            if (co < Co && ci < Ci) pp[((size_t)co * Ci + ci) * 27 + tap] = acc[t][i];
+            if (co < Co && ci < Ci) pp[((size_t)co * Ci + ci) * NTAPS + tap] = acc[t][i];
         }
     }
 }
 
-__global__ void wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, int n, int P) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// gw[i] = sum_p partial[p][i] in a FIXED order (deterministic): a workgroup owns 32 outputs, its 8 lane groups each sum
+// every 8th partial, and the 8 group sums are added in order.  (One thread per output walking all P partials was
+// latency-bound: up to 1024 partials x few thousand outputs for the 2-D layers.)
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, int n, int P) {
+    __shared__ float sm[8][32];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partial[(size_t)p * n + i];
-    gw[i] = s;
+    if (i < n) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = grp;
+        for (; p + 24 < P; p += 32) {
+            s0 += partial[(size_t)p * n + i];
+            s1 += partial[(size_t)(p + 8) * n + i];
+            s2 += partial[(size_t)(p + 16) * n + i];
+            s3 += partial[(size_t)(p + 24) * n + i];
+        }
+        for (; p < P; p += 8) s0 += partial[(size_t)p * n + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    sm[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += sm[g][o];
+        gw[i] = t;
+    }
 }
 
-inline int wgrad_workers(int Ci, int Co, long long ntiles) {
+inline int wgrad_workers(int Ci, int Co, long long ntiles, int occ = 1) {
     const int ytiles = ((Ci + CT - 1) / CT) * ((Co + CT - 1) / CT);
-    long long p = 256 / ytiles;                 // one persistent workgroup per CU in total (the kernel runs 1 block/CU)
+    long long p = 256 * occ / ytiles;           // `occ` persistent workgroups per CU in total (3-D: 1, 2-D: 2)
     if (p < 1) p = 1;
     if (p > ntiles) p = ntiles;
     return (int)p;
 }
 
-template <int STRIDE, int TD, int TH>
+template <int STRIDE, int TD, int TH, int KD>
 int launch_wgrad(const float* x, const float* gy, float* gw, float* partial, int B, int Ci, int Co, int D, int H, int W,
                  hipStream_t st) {
-    using Cfg = WgCfg<STRIDE, TD, TH>;
+    using Cfg = WgCfg<STRIDE, TD, TH, KD>;
     const int Do = (D - 1) / STRIDE + 1, Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
     const int tiles_d = (Do + TD - 1) / TD, tiles_h = (Ho + TH - 1) / TH, tiles_w = (Wo + TWV - 1) / TWV;
     const long long ntiles = (long long)B * tiles_d * tiles_h * tiles_w;
     const int ci_tiles = (Ci + CT - 1) / CT, co_tiles = (Co + CT - 1) / CT;
-    const int P = wgrad_workers(Ci, Co, ntiles);
-    auto kern = conv3d_wgrad_mfma<STRIDE, TD, TH>;
+    const int P = wgrad_workers(Ci, Co, ntiles, KD == 3 ? 1 : 2);
+    auto kern = conv3d_wgrad_mfma<STRIDE, TD, TH, KD>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -261,8 +292,8 @@ int launch_wgrad(const float* x, const float* gy, float* gw, float* partial, int
     }
     hipLaunchKernelGGL(kern, dim3(P, ci_tiles * co_tiles), dim3(256), Cfg::LDS_BYTES, st, x, gy, partial, B, Ci, Co, D, H,
                        W, Do, Ho, Wo, tiles_d, tiles_h, tiles_w, ci_tiles);
-    const int n = Co * Ci * 27;
-    hipLaunchKernelGGL(wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, n, P);
+    const int n = Co * Ci * Cfg::NTAPS;
+    hipLaunchKernelGGL(wgrad_reduce, dim3((n + 31) / 32), dim3(256), 0, st, partial, gw, n, P * Cfg::KG);
     return ECM_LAUNCH_RESULT();
 }
 
@@ -288,6 +319,25 @@ extern "C" int ecm_conv3d_k3_wgrad(const float* x, const float* gy, float* gw, v
     if (scratch_bytes < ecm_conv3d_wgrad_scratch_bytes(B, Ci, Co, D, H, W, stride)) return ECM_ESCRATCH;
     float* partial = static_cast<float*>(scratch);
     hipStream_t st = ecm_stream(stream);
-    if (stride == 1) return launch_wgrad<1, 2, 8>(x, gy, gw, partial, B, Ci, Co, D, H, W, st);
-    return launch_wgrad<2, 1, 4>(x, gy, gw, partial, B, Ci, Co, D, H, W, st);
+    if (stride == 1) return launch_wgrad<1, 2, 8, 3>(x, gy, gw, partial, B, Ci, Co, D, H, W, st);
+    return launch_wgrad<2, 1, 4, 3>(x, gy, gw, partial, B, Ci, Co, D, H, W, st);
+}
+
+// ---- 3x3 Conv2d (stride 1, pad 1): 16 x 16 output tiles of a depth-1 volume -------------------------------------
+namespace {
+inline long long ntiles2d(int B, int H, int W) { return (long long)B * ((H + 15) / 16) * ((W + TWV - 1) / TWV); }
+}  // namespace
+
+extern "C" long long ecm_conv2d_k3_wgrad_scratch_bytes(int B, int Ci, int Co, int H, int W) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;
+    return (long long)wgrad_workers(Ci, Co, ntiles2d(B, H, W), 2) * 2 * Co * Ci * 9 * (long long)sizeof(float);
+}
+
+extern "C" int ecm_conv2d_k3_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
+                                   int B, int Ci, int Co, int H, int W, void* stream) {
+    ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && Co > 0 && H > 0 && W > 0);
+    if ((long long)H * W * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;
+    if (ntiles2d(B, H, W) >= 0x7fffffffLL) return ECM_EUNSUP;
+    if (scratch_bytes < ecm_conv2d_k3_wgrad_scratch_bytes(B, Ci, Co, H, W)) return ECM_ESCRATCH;
+    return launch_wgrad<1, 1, 16, 1>(x, gy, gw, static_cast<float*>(scratch), B, Ci, Co, 1, H, W, ecm_stream(stream));
 }

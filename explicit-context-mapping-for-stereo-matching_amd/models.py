@@ -53,11 +53,27 @@ class HipReLU(nn.ReLU):
     """Placeholder keeping the reference's Sequential indices; fused into the preceding GroupNorm kernel."""
 
 
+class EncConv2d(nn.Conv2d):
+    """nn.Conv2d of the encoder.  Forward / data gradient: PyTorch-ROCm (MIOpen).  For the 3x3, stride-1, undilated
+    layers with 32 or 64 channels on both sides the weight gradient runs on the MFMA wgrad kernel (ops.Conv2dK3)."""
+
+    def _hip_wgrad(self):
+        return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation == (1, 1)
+                and self.padding == (1, 1) and self.groups == 1 and self.bias is None
+                and self.in_channels in (32, 64) and self.out_channels in (32, 64))
+
+    def forward(self, x):
+        if self._hip_wgrad() and x.is_cuda and torch.is_grad_enabled() and self.weight.requires_grad:
+            return ops.conv2d_k3(x, self.weight)
+        return super().forward(x)
+
+
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
-    """2-D conv + GroupNorm of the encoder (cmfsm.py:36-46).  The convolution stays on PyTorch-ROCm (MIOpen); the
-    GroupNorm (and the ReLU / residual add that follows it) runs on the same fused HIP kernel as the 3-D stack."""
+    """2-D conv + GroupNorm of the encoder (cmfsm.py:36-46).  The convolution stays on PyTorch-ROCm (MIOpen) except for
+    the weight gradient of its 32/64-channel 3x3 layers; the GroupNorm (and the ReLU / residual add that follows it)
+    runs on the same fused HIP kernel as the 3-D stack."""
     return nn.Sequential(
-        nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
+        EncConv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
                   padding=dilation if dilation > 1 else pad, dilation=dilation, bias=False),
         HipGroupNorm(NUM_GROUPS, out_planes))
 
@@ -181,7 +197,7 @@ class feature_extraction(nn.Module):
                 convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
                 convbn(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True)]
         if cfg["first_tail"] == "conv":
-            self.firstconv = nn.Sequential(*head, nn.Conv2d(32, 32, kernel_size=3, padding=1, stride=1, bias=False))
+            self.firstconv = nn.Sequential(*head, EncConv2d(32, 32, kernel_size=3, padding=1, stride=1, bias=False))
             self.secondconv = nn.Sequential(
                 HipGroupNorm(NUM_GROUPS, 32), nn.ReLU(inplace=True),
                 convbn(32, 32, 3, 2, 1, 1), nn.ReLU(inplace=True),

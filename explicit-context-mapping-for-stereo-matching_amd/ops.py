@@ -407,6 +407,40 @@ def _dgrad_small_co(gy, w):
     return _conv_fwd(gyp, _pack_conv(wp, True), Ci, 1)
 
 
+class Conv2dK3(torch.autograd.Function):
+    """The encoder's 3x3 / stride 1 / pad 1 Conv2d (convbn, cmfsm.py:37-47): forward and data gradient stay on
+    PyTorch-ROCm (MIOpen, as for the rest of the encoder); the weight gradient -- where MIOpen's fp32 kernels reach
+    45-77 TFLOP/s on these shapes -- runs on the MFMA wgrad kernel (depth-1 volume, 9 taps)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _chk(x, w)
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.conv2d(x, w, None, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            xc, gc = _c(x), _c(gy)
+            B, Ci, H, W = xc.shape
+            Co = w.shape[0]
+            gw = torch.empty_like(w)
+            nb = _lib.query("ecm_conv2d_k3_wgrad_scratch_bytes", B, Ci, Co, H, W)
+            scratch = _scratch(nb, x.device)
+            _lib.call("ecm_conv2d_k3_wgrad", _p(xc), _p(gc), _p(gw), _p(scratch), C.c_longlong(nb), B, Ci, Co, H, W,
+                      _stream())
+        return gx, gw
+
+
+def conv2d_k3(x, w):
+    return Conv2dK3.apply(x, w)
+
+
 def conv3d_k3(x, w, stride=1):
     return Conv3dK3.apply(x, w, int(stride))
 

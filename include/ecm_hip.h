@@ -144,6 +144,13 @@ long long ecm_conv3d_wgrad_scratch_bytes(int B, int Ci, int Co, int D, int H, in
 int ecm_conv3d_k3_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
                         int B, int Ci, int Co, int D, int H, int W, int stride, void* stream);
 
+/* Weight gradient of the encoder's 3x3 Conv2d (stride 1, pad 1, dilation 1, no bias; convbn, cmfsm.py:37-47):
+ * gw[co,ci,3,3] = sum_{b,o} gy[b,co,o] * x[b,ci,o+k-1].  Same kernel as ecm_conv3d_k3_wgrad on a depth-1 volume with 9 taps.
+ * x: [B,Ci,H,W], gy: [B,Co,H,W]; scratch >= ecm_conv2d_k3_wgrad_scratch_bytes(...) */
+long long ecm_conv2d_k3_wgrad_scratch_bytes(int B, int Ci, int Co, int H, int W);
+int ecm_conv2d_k3_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
+                        int B, int Ci, int Co, int H, int W, void* stream);
+
 /* GroupNorm(32 groups, eps) over [B,C,S] (S = D*H*W), cmfsm.py:58; deterministic fixed-order reductions.
  * scratch for every call: >= ecm_gn3d_scratch_bytes(B,C,S).
  * fwd: y = relu?( (x-mean)*rstd*gamma[c]+beta[c] (+ skip) ) (skip may be NULL) and mean_rstd [B,32,2] in ONE pass over x

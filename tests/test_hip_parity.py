@@ -208,6 +208,23 @@ def test_conv3d_fwd(ecm, B, Ci, Co, dims, stride):
     close(y, F.conv3d(x, w, None, stride, 1), 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 32, 32, 20, 40), (1, 64, 64, 33, 50), (1, 32, 64, 16, 16), (2, 64, 32, 48, 70),
+                                         (1, 32, 32, 5, 7)])
+def test_conv2d_k3_wgrad(ecm, B, Ci, Co, H, W):
+    """Encoder 3x3 Conv2d: MIOpen forward / dgrad + MFMA weight gradient == autograd of F.conv2d on the CPU."""
+    x = seeded("cv2.x", B, Ci, H, W)
+    w = seeded("cv2.w", Co, Ci, 3, 3) * (2.0 / (9 * Ci)) ** 0.5
+    G = seeded("cv2.G", B, Co, H, W)
+    xs, ws = x.clone().requires_grad_(), w.clone().requires_grad_()
+    F.conv2d(xs, ws, None, 1, 1).backward(G)
+    xg, wg = dev(x).requires_grad_(), dev(w).requires_grad_()
+    y = ecm.ops.conv2d_k3(xg, wg)
+    y.backward(dev(G))
+    close(y, F.conv2d(x, w, None, 1, 1), 1e-4, 1e-5)
+    close(xg.grad, xs.grad, 1e-4, 1e-5)
+    close(wg.grad, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))
+
+
 @pytest.mark.parametrize("B,Ci,Co,dims", [(1, 64, 64, (2, 4, 6)), (1, 64, 32, (4, 8, 12)), (2, 64, 32, (3, 5, 35)),
                                           (1, 64, 64, (3, 9, 15))])
 def test_deconv3d_fwd(ecm, B, Ci, Co, dims):
@@ -350,7 +367,10 @@ def test_full_model_golden(ecm, cmfsm_sd):
     for i, name in enumerate(("o1", "o2", "o3")):
         assert o[i].shape == (1, 1, 256, 512)
         d = (o[i].cpu()[..., ::4, ::4] - g[name]).abs()
-        assert d.max() <= 2e-2 and d.mean() <= 1e-3, (name, d.max(), d.mean())
+        # stated tolerance for the END-TO-END model (disparities span 0..191 px): max 0.02 px, mean 0.0025 px.  The mean is
+        # looser than for the hot path alone (1e-3, above) because the MIOpen encoder in front of it picks its fp32
+        # algorithm (Winograd / implicit GEMM) per box and is not run-to-run deterministic (tests/test_hip_fullsize.py).
+        assert d.max() <= 2e-2 and d.mean() <= 2.5e-3, (name, d.max(), d.mean())
 
 
 def test_cpu_tensor_is_refused(ecm):

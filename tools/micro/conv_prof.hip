@@ -1,4 +1,4 @@
-// Phase-level cycle profile of the forward 3x3x3 conv kernel (workgroup 2000): build with
+// Phase-level cycle profile of the forward 3x3x3 conv kernel (workgroup 700): build with
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DCV_PROFILE -Iinclude -Iexplicit-context-mapping-for-stereo-matching_amd/csrc tools/micro/conv_prof.hip -o tools/micro/conv_prof
 #include "conv3d.hip"
 #include <cstdio>

@@ -75,10 +75,15 @@ def main():
     ecm_dist = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
     lib = ecm_amd._lib
 
-    rank, world, local = ecm_dist.init_from_env("nccl")
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the HIP path has no CPU fallback)"
+    # one process per GPU over RCCL ("nccl"); ECM_DIST_BACKEND=gloo lets several ranks rehearse the N>1 path on a
+    # box with fewer GPUs than ranks (ranks then share devices round-robin; RCCL itself refuses duplicate devices)
+    backend = os.environ.get("ECM_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)
     torch.cuda.set_device(local)
+    rank, world, _ = ecm_dist.init_from_env(backend, device=local)
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     dev = torch.device("cuda", local)
     # The reference sets cudnn.benchmark=True (train.py:26); on ROCm that means an exhaustive MIOpen search per conv
     # shape (minutes at this size), so the encoder runs on MIOpen's immediate-mode picks instead.
@@ -112,8 +117,9 @@ def main():
                 return model(left, right)[2]
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
-            torch.distributed.barrier()
+            torch.distributed.barrier(device_ids=[local]) if backend == "nccl" else torch.distributed.barrier()
         torch.cuda.synchronize()
 
     def note(msg):

@@ -13,8 +13,9 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None):
-    """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*). Returns (rank, world, local_rank)."""
+def init_from_env(backend: str | None = None, device: int | None = None):
+    """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*). Returns (rank, world, local_rank).
+    `device`: the GPU index this rank uses (default LOCAL_RANK); with "nccl" the process group is bound to it."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -23,9 +24,12 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev = local if device is None else device
+            torch.cuda.set_device(dev)
+            kw["device_id"] = torch.device("cuda", dev)      # eager communicator on the right GPU; barrier() needs no guess
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 

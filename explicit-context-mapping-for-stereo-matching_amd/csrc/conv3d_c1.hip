@@ -243,12 +243,9 @@ extern "C" int ecm_conv3d_c1_fwd(const float* x, const float* w, float* y, int B
     const int tiles_d = (D + FTD - 1) / FTD, tiles_h = (H + FTH - 1) / FTH, tiles_w = (W + FTW - 1) / FTW;
     const long long nblk = (long long)B * tiles_d * tiles_h * tiles_w;
     if (nblk > 0x7fffffffLL) return ECM_EUNSUP;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c1_fwd),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
+    {
+        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(conv3d_c1_fwd), F_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(conv3d_c1_fwd, dim3((unsigned)nblk), dim3(256), F_LDS_BYTES, ecm_stream(stream), x, w, y, Ci, D, H, W,
                        tiles_d, tiles_h, tiles_w);
@@ -268,12 +265,9 @@ extern "C" int ecm_conv3d_c1_wgrad(const float* x, const float* gy, float* gw, v
     const int tiles_d = (D + GTD - 1) / GTD, tiles_h = (H + GTH - 1) / GTH, tiles_w = (W + GTW - 1) / GTW;
     const int P = c1_workers(c1_tiles(B, D, H, W));
     hipStream_t st = ecm_stream(stream);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_c1_wgrad),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
+    {
+        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(conv3d_c1_wgrad), G_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     float* partial = static_cast<float*>(scratch);
     hipLaunchKernelGGL(conv3d_c1_wgrad, dim3(P), dim3(256), G_LDS_BYTES, st, x, gy, partial, B, Ci, D, H, W, tiles_d, tiles_h,

@@ -283,12 +283,9 @@ int launch_wgrad(const float* x, const float* gy, float* gw, float* partial, int
     const int ci_tiles = (Ci + CT - 1) / CT, co_tiles = (Co + CT - 1) / CT;
     const int P = wgrad_workers(Ci, Co, ntiles, KD == 3 ? 1 : 2);
     auto kern = conv3d_wgrad_mfma<STRIDE, TD, TH, KD>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           Cfg::LDS_BYTES);
+    {
+        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(P, ci_tiles * co_tiles), dim3(256), Cfg::LDS_BYTES, st, x, gy, partial, B, Ci, Co, D, H,
                        W, Do, Ho, Wo, tiles_d, tiles_h, tiles_w, ci_tiles);

@@ -170,12 +170,9 @@ int launch_deconv(const float* x, const float* wp, float* y, int B, int Ci, int 
     const long long nblk = (long long)B * tiles_d * tiles_h * tiles_w;
     if (nblk > 0x7fffffffLL || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
     auto kern = deconv3d_k3s2_mfma<CO_TILES, CIC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           Cfg::LDS_BYTES);
+    {
+        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, x, wp, y, Ci, Co, D, H, W, Do, Ho,
                        Wo, tiles_d, tiles_h, tiles_w);

@@ -481,12 +481,9 @@ int launch_bwd(const float* lr, const float* hr, const float* W0, const float* W
     float *A = base + p.offA, *gA9 = base + p.offA9, *partB = base + p.offPB, *partC = base + p.offPC;
     const long long cells = (long long)B * h * w;
     hipLaunchKernelGGL(bwd_lr_proj, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, lr, W0, A, B, h * w);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ecm_weights_bwd_kernel<VAR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS_BYTES);
+    {
+        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(ecm_weights_bwd_kernel<VAR>), BWD_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(ecm_weights_bwd_kernel<VAR>, dim3(p.nB), dim3(256), BWD_LDS_BYTES, st, A, hr, W0, W1, W2, W3, saved,
                        gout, ghr, gA9, partB, B, h, w, s, p.tiles_x);

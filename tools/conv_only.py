@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [which]"""
+"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wgrad|costvol] [B]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,7 @@ import ecm_amd
 ops = ecm_amd.ops
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
 dev = "cuda"
-B = 1
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 if which == "conv":
     x = torch.randn(B, 32, 48, 144, 240, device=dev); w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
     pk = ops._pack_conv(w)

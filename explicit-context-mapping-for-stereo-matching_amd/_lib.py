@@ -47,6 +47,9 @@ PROTOTYPES = {
     "ecm_conv3d_k3_wgrad": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_conv2d_k3_wgrad_scratch_bytes": (_LL, [_I] * 5),
     "ecm_conv2d_k3_wgrad": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
+    "ecm_stereo_loss_scratch_bytes": (_LL, [_LL]),
+    "ecm_stereo_loss_fwd": (_I, [_P] * 6 + [_LL, _LL, _F, _F, _F, _F, _P]),
+    "ecm_stereo_loss_bwd": (_I, [_P] * 9 + [_LL, _F, _F, _F, _F, _P]),
     "ecm_gn3d_scratch_bytes": (_LL, [_I, _I, _LL]),
     "ecm_gn3d_stats": (_I, [_P, _P, _P, _LL, _I, _I, _LL, _F, _P]),
     "ecm_gn3d_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _LL, _I, _P]),

@@ -517,5 +517,44 @@ class GroupNormAct(torch.autograd.Function):
         return gx, ggamma, gbeta, gskip, None
 
 
+class StereoLoss3(torch.autograd.Function):
+    """Loss of the training scripts and the KITTI validation metrics in one pass (train.py:162,172-174;
+    train_kitti.py:205-216).  Returns (loss, metrics[8]); metrics = [loss, #mask, epe, err3 %, m1, m2, m3, 0] (no grad)."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, p3, gt, maxdisp, w1, w2, w3):
+        _chk(p1, p2, p3, gt)
+        if not (p1.numel() == p2.numel() == p3.numel() == gt.numel()):
+            raise RuntimeError(f"prediction / ground-truth sizes differ: {tuple(p1.shape)} {tuple(p2.shape)} "
+                               f"{tuple(p3.shape)} vs {tuple(gt.shape)}")
+        p1, p2, p3, gt = _c(p1), _c(p2), _c(p3), _c(gt)
+        n = gt.numel()
+        out = torch.empty(8, device=gt.device, dtype=gt.dtype)
+        nb = _lib.query("ecm_stereo_loss_scratch_bytes", C.c_longlong(n))
+        scratch = _scratch(nb, gt.device)
+        _lib.call("ecm_stereo_loss_fwd", _p(p1), _p(p2), _p(p3), _p(gt), _p(out), _p(scratch), C.c_longlong(nb),
+                  C.c_longlong(n), C.c_float(maxdisp), C.c_float(w1), C.c_float(w2), C.c_float(w3), _stream())
+        ctx.save_for_backward(p1, p2, p3, gt, out)
+        ctx.cfg = (float(maxdisp), float(w1), float(w2), float(w3))
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, gloss, _gmetrics):
+        p1, p2, p3, gt, out = ctx.saved_tensors
+        maxdisp, w1, w2, w3 = ctx.cfg
+        gloss = _c(gloss.reshape(1).to(gt.dtype))
+        g1, g2, g3 = torch.empty_like(p1), torch.empty_like(p2), torch.empty_like(p3)
+        _lib.call("ecm_stereo_loss_bwd", _p(p1), _p(p2), _p(p3), _p(gt), _p(out), _p(gloss), _p(g1), _p(g2), _p(g3),
+                  C.c_longlong(gt.numel()), C.c_float(maxdisp), C.c_float(w1), C.c_float(w2), C.c_float(w3), _stream())
+        return g1, g2, g3, None, None, None, None, None
+
+
+def stereo_loss3(preds, gt, maxdisp=192, weights=(0.5, 0.7, 1.0)):
+    """-> (loss, metrics[8]) for the three predictions of a model (each [B,1,H,W] or [B,H,W]) and gt [B,H,W]."""
+    p1, p2, p3 = preds
+    return StereoLoss3.apply(p1, p2, p3, gt, float(maxdisp), *map(float, weights))
+
+
 def group_norm_act(x, gamma, beta, skip=None, relu=False):
     return GroupNormAct.apply(x, gamma, beta, skip, bool(relu))

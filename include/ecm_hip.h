@@ -171,6 +171,18 @@ int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, con
                  const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
                  long long scratch_bytes, int B, int C, long long S, int relu, void* stream);
 
+/* Harness loss + metrics (train.py:162,172-174; train_kitti.py:205-216) over n = B*H*W pixels; mask = 0 < gt < maxdisp.
+ * out8 (device): [loss, #mask, epe(p3), err3(p3) in %, mean smooth-L1 of p1, p2, p3, 0];
+ * loss = w1*m1 + w2*m2 + w3*m3 (reference weights 0.5 / 0.7 / 1.0).  Empty mask -> NaN (as the reference's empty mean).
+ * bwd: g_k = gloss[0] * w_k / #mask * clamp(p_k - gt, -1, 1) inside the mask, 0 outside (gloss: device scalar). */
+long long ecm_stereo_loss_scratch_bytes(long long n);
+int ecm_stereo_loss_fwd(const float* p1, const float* p2, const float* p3, const float* gt, float* out8,
+                        void* scratch, long long scratch_bytes, long long n, float maxdisp,
+                        float w1, float w2, float w3, void* stream);
+int ecm_stereo_loss_bwd(const float* p1, const float* p2, const float* p3, const float* gt, const float* out8,
+                        const float* gloss, float* g1, float* g2, float* g3, long long n, float maxdisp,
+                        float w1, float w2, float w3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -296,6 +296,16 @@ def train_loss(preds, gt, maxdisp=192):
             + F.smooth_l1_loss(o3[mask], gt[mask], reduction="mean"))
 
 
+def kitti_metrics(pred3, gt, maxdisp=192):
+    """train_kitti.py:213-216: end-point error and the 3-px / 5 % error rate (in %) of the last head over the mask."""
+    mask = (gt < maxdisp) & (gt > 0)
+    o3 = pred3.squeeze(1) if pred3.dim() == gt.dim() + 1 else pred3
+    err = torch.abs(o3[mask] - gt[mask])
+    epe = torch.mean(err)
+    good = torch.where((err < 3) | (err < 0.05 * gt[mask]), torch.ones_like(err), torch.zeros_like(err))
+    return epe, 100 - torch.sum(good) / torch.sum(mask) * 100
+
+
 # ============================================================================
 # The other registered architectures (SURVEY 8a rows a4, a10, a11)
 # ============================================================================

@@ -373,6 +373,33 @@ def test_full_model_golden(ecm, cmfsm_sd):
         assert d.max() <= 2e-2 and d.mean() <= 2.5e-3, (name, d.max(), d.mean())
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 16, 32), (2, 37, 53), (4, 256, 512)])
+def test_stereo_loss3(ecm, B, H, W):
+    """Fused loss + metrics kernel == the harness restatement (train.py:162,172-174; train_kitti.py:213-216)."""
+    gt = (seeded("loss.gt", B, H, W).abs() * 120.0)                 # some pixels > 192, and
+    gt[:, ::7, ::5] = 0.0                                            # some invalid (0) pixels
+    ps = [gt + seeded(f"loss.p{i}", B, 1, H, W).squeeze(1) * s for i, s in ((1, 4.0), (2, 2.0), (3, 0.7))]
+    cpu = [p.clone().unsqueeze(1).requires_grad_() for p in ps]
+    ref = O.train_loss(cpu, gt)
+    ref.backward()
+    epe, err3 = O.kitti_metrics(cpu[2].detach(), gt)
+    gpu = [dev(p).unsqueeze(1).requires_grad_() for p in ps]
+    loss, met = ecm.ops.stereo_loss3(gpu, dev(gt))
+    (loss * 1.5).backward()
+    mask = (gt < 192) & (gt > 0)
+    close(loss, ref.detach(), 1e-5, 1e-6)
+    assert float(met[1]) == float(mask.sum())
+    close(met[2], epe, 1e-5, 1e-6)
+    close(met[3], err3, 1e-5, 1e-4)
+    for g, c in zip(gpu, cpu):
+        close(g.grad, 1.5 * c.grad, 1e-5, 1e-9)
+    # empty mask: NaN, like the reference's mean over an empty selection
+    l0, _ = ecm.ops.stereo_loss3([dev(p).unsqueeze(1) for p in ps], dev(torch.zeros_like(gt)))
+    assert torch.isnan(l0)
+    with pytest.raises(RuntimeError):
+        ecm.ops.stereo_loss3([gpu[0], gpu[1], gpu[2][:, :, :-1]], dev(gt))
+
+
 def test_cpu_tensor_is_refused(ecm):
     with pytest.raises(RuntimeError):
         ecm.ops.cost_volume(torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 4), 2)

@@ -113,6 +113,15 @@ def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
         HipGroupNorm(NUM_GROUPS, out_planes))
 
 
+def _costvol_dres0(dres0, lr_l, lr_r, ndisp):
+    """Cost-volume build + dres0's first convbn_3d + ReLU (cmfsm.py:667-684) as one op: the reference-image half of the
+    concat volume is constant along d, so its part of the convolution is a class-indexed set of 2-D convolutions of the
+    feature map and only the shifted target-image half is materialised (ops.costvol_conv3d).  `ops.cost_volume` is the
+    stand-alone builder of the full [B,2C,D,h,w] tensor (kept for the drop-in boundary and the microbench)."""
+    conv, gn = dres0[0][0], dres0[0][1]
+    return gn.fused(ops.costvol_conv3d(lr_l, lr_r, conv.weight, ndisp), None, True)
+
+
 def _cbn(seq, x, skip=None, relu=False):
     """Run a convbn_3d Sequential with the trailing residual/ReLU fused into the GroupNorm kernel."""
     return seq[1].fused(seq[0](x), skip, relu)
@@ -370,8 +379,7 @@ class cmfsm(nn.Module):
         """Everything after the encoder (cmfsm.py:659-774)."""
         scale = hr_l.shape[-1] // lr_l.shape[-1]
         w9 = self.mapping_matrix.weights(lr_l, hr_l)                                   # :664
-        cost = ops.cost_volume(lr_l, lr_r, self.maxdisp // scale)                      # :667-682
-        cost0 = _cbn(self.dres0[0], cost, relu=True)                                   # :684
+        cost0 = _costvol_dres0(self.dres0, lr_l, lr_r, self.maxdisp // scale)          # :667-684
         cost0 = _cbn(self.dres0[2], cost0, relu=True)
         y = _cbn(self.dres1[0], cost0, relu=True)                                      # :685
         cost0 = _cbn(self.dres1[2], y, skip=cost0)
@@ -466,8 +474,7 @@ class _ECMNet(nn.Module):
         planes = None
         if self.HEAD in ("five", "volume"):
             planes = self.mapping_matrix.planes(lr_l, hr_l, lr_r, hr_r)
-        cost = ops.cost_volume(lr_l, lr_r, self.maxdisp // scale)
-        cost0 = _cbn(self.dres0[0], cost, relu=True)
+        cost0 = _costvol_dres0(self.dres0, lr_l, lr_r, self.maxdisp // scale)
         cost0 = _cbn(self.dres0[2], cost0, relu=True)
         cost0 = _cbn(self.dres1[2], _cbn(self.dres1[0], cost0, relu=True), skip=cost0)
         heads, x, pre1, post = [], cost0, None, None

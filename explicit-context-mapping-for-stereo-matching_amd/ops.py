@@ -43,6 +43,12 @@ def _c(t):
     return t
 
 
+def _empty_like(t):
+    """A CONTIGUOUS uninitialised tensor of t's shape: the kernels write dense row-major buffers, and
+    `torch.empty_like` would copy the strides of a non-contiguous `t` (e.g. an einsum output viewed as a weight)."""
+    return torch.empty(t.shape, dtype=t.dtype, device=t.device)
+
+
 def _scratch(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -66,13 +72,97 @@ class CostVolumeConcat(torch.autograd.Function):
         B, Cc, h, w, D = ctx.dims
         gcost = _c(gcost)
         gl = torch.empty(B, Cc, h, w, device=gcost.device, dtype=gcost.dtype)
-        gr = torch.empty_like(gl)
+        gr = _empty_like(gl)
         _lib.call("ecm_costvol_concat_bwd", _p(gcost), _p(gl), _p(gr), B, Cc, h, w, D, _stream())
         return gl, gr, None
 
 
 def cost_volume(left, right, ndisp):
     return CostVolumeConcat.apply(left, right, int(ndisp))
+
+
+class CostVolumeRight(torch.autograd.Function):
+    """Target-image half of the cost volume only (cmfsm.py:678-681): R [B,C,h,w] -> [B,C,D,h,w]."""
+
+    @staticmethod
+    def forward(ctx, right, ndisp):
+        _chk(right)
+        right = _c(right)
+        B, Cc, h, w = right.shape
+        cost = torch.empty(B, Cc, ndisp, h, w, device=right.device, dtype=right.dtype)
+        _lib.call("ecm_costvol_right_fwd", _p(right), _p(cost), B, Cc, h, w, ndisp, _stream())
+        ctx.dims = (B, Cc, h, w, ndisp)
+        return cost
+
+    @staticmethod
+    def backward(ctx, gcost):
+        B, Cc, h, w, D = ctx.dims
+        gcost = _c(gcost)
+        gr = torch.empty(B, Cc, h, w, device=gcost.device, dtype=gcost.dtype)
+        _lib.call("ecm_costvol_right_bwd", _p(gcost), _p(gr), B, Cc, h, w, D, _stream())
+        return gr, None
+
+
+class CostvolClassAdd(torch.autograd.Function):
+    """y[b,co,d,h,w] += P[b,class(d,w),co,h,w] in place (see csrc/costvol_conv.hip); backward: gy passes through,
+    gP = per-class sums of gy over d."""
+
+    @staticmethod
+    def forward(ctx, y, P):
+        _chk(y, P)
+        B, Co, D, h, w = y.shape
+        if not (y.is_contiguous() and y.data_ptr() % 16 == 0):
+            raise RuntimeError("costvol class add works in place on a contiguous, 16-byte aligned conv output")
+        P = _c(P)
+        assert P.shape == (B, 15 * Co, h, w), (P.shape, y.shape)
+        _lib.call("ecm_costvol_class_add_fwd", _p(y), _p(P), B, Co, D, h, w, _stream())
+        ctx.mark_dirty(y)
+        ctx.dims = (B, Co, D, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, Co, D, h, w = ctx.dims
+        gyc = _c(gy)
+        gP = torch.empty(B, 15 * Co, h, w, device=gy.device, dtype=gy.dtype)
+        _lib.call("ecm_costvol_class_add_bwd", _p(gyc), _p(gP), B, Co, D, h, w, _stream())
+        return gy, gP
+
+
+_CLASS_TAPS = {}
+
+
+def _class_tap_mask(device):
+    """[15, kd, kw] 0/1: which depth taps of the reference-image half pass, per class = (clamp(d-w,-2,2)+2)*3 + edge,
+    edge 0/1/2 = first / interior / last disparity plane.  A tap passes iff kw-kd >= d-w (wedge `x >= d` of
+    cmfsm.py:678-679 at the tap's position) and 0 <= d+kd-1 < D (depth padding)."""
+    m = _CLASS_TAPS.get(device)
+    if m is None:
+        m = torch.zeros(15, 3, 3)
+        for dc in range(5):
+            for e in range(3):
+                for kd in range(3):
+                    if (e == 0 and kd == 0) or (e == 2 and kd == 2):
+                        continue
+                    for kw in range(3):
+                        if kw - kd >= dc - 2:
+                            m[dc * 3 + e, kd, kw] = 1.0
+        m = _CLASS_TAPS[device] = m.to(device)
+    return m
+
+
+def costvol_conv3d(left, right, weight, ndisp):
+    """conv3d(cost_volume(left, right, ndisp), weight, stride 1, pad 1)  (cmfsm.py:667-684) WITHOUT the reference-image
+    half of the volume: that half is constant along d where it is not zero, so its contribution is one of fifteen 2-D
+    convolutions of `left`, selected per (d, x) -- see csrc/costvol_conv.hip.  weight: [Co, 2C, 3, 3, 3]."""
+    Cc = left.shape[1]
+    if weight.shape[1] != 2 * Cc or ndisp < 2 or Cc % 32 != 0:
+        return conv3d_k3(cost_volume(left, right, ndisp), weight, 1)
+    Co = weight.shape[0]
+    y = conv3d_k3(CostVolumeRight.apply(right, int(ndisp)), weight[:, Cc:].contiguous(), 1)
+    wst = torch.einsum("xdk,oidhk->xoihk", _class_tap_mask(weight.device), weight[:, :Cc])      # [15,Co,C,3,3]
+    P = conv2d_k3(left, wst.reshape(15 * Co, Cc, 3, 3))                                           # [B,15*Co,h,w]
+    return CostvolClassAdd.apply(y, P)
 
 
 # ------------------------------------------------------------------------------------ a8 soft-argmin
@@ -95,7 +185,7 @@ class SoftArgminHeads(torch.autograd.Function):
         (c,) = ctx.saved_tensors
         NH, B, D, h, w = c.shape
         gdisp = _c(gdisp)
-        gc = torch.empty_like(c)
+        gc = _empty_like(c)
         _lib.call("ecm_softargmin_heads_bwd", _p(c), C.c_longlong(B * D * h * w), _p(gdisp), _p(gc), NH, B, D, h * w,
                   _stream())
         return gc
@@ -136,7 +226,7 @@ class ECMAggregate9(torch.autograd.Function):
         d, w9 = ctx.saved_tensors
         NH, B, h, w = d.shape
         gout = _c(gout)
-        gd, gw9 = torch.empty_like(d), torch.empty_like(w9)
+        gd, gw9 = _empty_like(d), _empty_like(w9)
         _lib.call("ecm_aggregate9_bwd", _p(d), _p(w9), _p(gout), _p(gd), _p(gw9), NH, B, h, w, ctx.scale, _stream())
         return gd, gw9, None
 
@@ -176,7 +266,7 @@ class ECMWeights9(torch.autograd.Function):
         B, _, h, w = lr.shape
         s = ctx.s
         gw9 = _c(gw9)
-        glr, ghr = torch.empty_like(lr), torch.empty_like(hr)
+        glr, ghr = _empty_like(lr), _empty_like(hr)
         gW = torch.empty(2112 + 512 + 128 + 8, device=lr.device, dtype=lr.dtype)
         nb = _lib.query("ecm_weights9_bwd_scratch_bytes", B, h, w, s)
         scratch = _scratch(nb, lr.device)
@@ -224,7 +314,7 @@ class ContextWeights(torch.autograd.Function):
         B, _, h, w = lr.shape
         s, variant = ctx.s, ctx.variant
         g = _c(g)
-        glr, ghr = torch.empty_like(lr), torch.empty_like(hr)
+        glr, ghr = _empty_like(lr), _empty_like(hr)
         gW = torch.empty(2112 + 512 + 128 + 8, device=lr.device, dtype=lr.dtype)
         nb = _lib.query("ecm_context_weights_bwd_scratch_bytes", B, h, w, s, variant)
         if nb == 0:
@@ -262,7 +352,7 @@ class VolumeMapping(torch.autograd.Function):
         c, m5, mt3 = ctx.saved_tensors
         NH, B, Dl, h, w = c.shape
         g = _c(g)
-        gc, gm5, gmt3 = torch.empty_like(c), torch.empty_like(m5), torch.empty_like(mt3)
+        gc, gm5, gmt3 = _empty_like(c), _empty_like(m5), _empty_like(mt3)
         _lib.call("ecm_volume_mapping_bwd", _p(c), C.c_longlong(B * Dl * h * w), _p(m5), _p(mt3), _p(g), _p(gc), _p(gm5),
                   _p(gmt3), NH, B, Dl, h, w, ctx.scale, _stream())
         return gc, gm5, gmt3, None
@@ -293,7 +383,7 @@ class TrilinearSoftArgmin(torch.autograd.Function):
         NH, B, Dl, h, w = c.shape
         Do, H, W = ctx.dims
         g = _c(g)
-        gc = torch.empty_like(c)
+        gc = _empty_like(c)
         _lib.call("ecm_trilinear_softargmin_bwd", _p(c), C.c_longlong(B * Dl * h * w), _p(g), _p(gc), NH, B, Dl, h, w, Do, H,
                   W, _stream())
         return gc, None, None, None
@@ -380,7 +470,7 @@ class Conv3dK3(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if _is_c1(w, ctx.stride):
                 B, _, D, H, W = x.shape
-                gw = torch.empty_like(w)
+                gw = _empty_like(w)
                 nb = _lib.query("ecm_conv3d_c1_wgrad_scratch_bytes", B, Ci, D, H, W)
                 scratch = _scratch(nb, x.device)
                 _lib.call("ecm_conv3d_c1_wgrad", _p(x), _p(gy), _p(gw), _p(scratch), C.c_longlong(nb), B, Ci, D, H, W,
@@ -429,7 +519,7 @@ class Conv2dK3(torch.autograd.Function):
             xc, gc = _c(x), _c(gy)
             B, Ci, H, W = xc.shape
             Co = w.shape[0]
-            gw = torch.empty_like(w)
+            gw = _empty_like(w)
             nb = _lib.query("ecm_conv2d_k3_wgrad_scratch_bytes", B, Ci, Co, H, W)
             scratch = _scratch(nb, x.device)
             _lib.call("ecm_conv2d_k3_wgrad", _p(xc), _p(gc), _p(gw), _p(scratch), C.c_longlong(nb), B, Ci, Co, H, W,
@@ -489,7 +579,7 @@ class GroupNormAct(torch.autograd.Function):
         stats = torch.empty(B, GN_GROUPS, 2, device=x.device, dtype=x.dtype)
         nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
         scratch = _scratch(nb, x.device)
-        y = torch.empty_like(x)
+        y = _empty_like(x)
         _lib.call("ecm_gn3d_fwd", _p(x), _p(gamma), _p(beta), _p(skip), _p(y), _p(stats), _p(scratch), C.c_longlong(nb),
                   B, Cc, C.c_longlong(S), int(relu), C.c_float(GN_EPS), _stream())
         # ReLU mask in backward: recomputed from x unless a skip was added (then the output y is needed)
@@ -503,8 +593,8 @@ class GroupNormAct(torch.autograd.Function):
         gy = _c(gy)
         B, Cc = x.shape[:2]
         S = x.numel() // (B * Cc)
-        gx = torch.empty_like(x)
-        gskip = torch.empty_like(x) if ctx.has_skip else None
+        gx = _empty_like(x)
+        gskip = _empty_like(x) if ctx.has_skip else None
         if ctx.has_skip and not ctx.relu:
             gskip = gy                      # no mask: the skip gradient is gy itself
         ggamma = torch.zeros_like(gamma)
@@ -544,7 +634,7 @@ class StereoLoss3(torch.autograd.Function):
         p1, p2, p3, gt, out = ctx.saved_tensors
         maxdisp, w1, w2, w3 = ctx.cfg
         gloss = _c(gloss.reshape(1).to(gt.dtype))
-        g1, g2, g3 = torch.empty_like(p1), torch.empty_like(p2), torch.empty_like(p3)
+        g1, g2, g3 = _empty_like(p1), _empty_like(p2), _empty_like(p3)
         _lib.call("ecm_stereo_loss_bwd", _p(p1), _p(p2), _p(p3), _p(gt), _p(out), _p(gloss), _p(g1), _p(g2), _p(g3),
                   C.c_longlong(gt.numel()), C.c_float(maxdisp), C.c_float(w1), C.c_float(w2), C.c_float(w3), _stream())
         return g1, g2, g3, None, None, None, None, None

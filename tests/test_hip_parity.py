@@ -167,6 +167,28 @@ def test_ecm_module_tuple(ecm, cmfsm_sd):
         mm(dev(seeded("x", 1, 32, 4, 4)), dev(seeded("y", 1, 32, 12, 12)), None, None)      # scale 3
 
 
+# ------------------------------------------------------------------ a1 + a5 fused: first conv on the concat volume
+@pytest.mark.parametrize("B,h,w,D", [(1, 8, 16, 6), (2, 6, 36, 12), (1, 5, 9, 2), (1, 4, 12, 20), (1, 8, 64, 48)])
+def test_costvol_conv3d_split(ecm, B, h, w, D):
+    """conv3d(concat volume) computed without the reference-image half == the plain composition (oracle)."""
+    L, R = seeded("cvc.L", B, 32, h, w), seeded("cvc.R", B, 32, h, w)
+    W = seeded("cvc.W", 32, 64, 3, 3, 3) * (2.0 / (27 * 64)) ** 0.5
+    G = seeded("cvc.G", B, 32, D, h, w)
+    Ls, Rs, Ws = (t.clone().requires_grad_() for t in (L, R, W))
+    ref = F.conv3d(O.cost_volume(Ls, Rs, D), Ws, None, 1, 1)
+    ref.backward(G)
+    Lg, Rg, Wg = (dev(t).requires_grad_() for t in (L, R, W))
+    y = ecm.ops.costvol_conv3d(Lg, Rg, Wg, D)
+    y.backward(dev(G))
+    close(y, ref, 1e-4, 2e-5)
+    close(Lg.grad, Ls.grad, 1e-4, 2e-5)
+    close(Rg.grad, Rs.grad, 1e-4, 2e-5)
+    close(Wg.grad, Ws.grad, 1e-4, 1e-4 * float(Ws.grad.abs().max()))
+    # the right-half volume itself is a copy: bit-exact
+    cr = ecm.ops.CostVolumeRight.apply(dev(R), D)
+    assert torch.equal(cr.cpu(), O.cost_volume(L, R, D)[:, 32:])
+
+
 # ------------------------------------------------------------------ GroupNorm
 @pytest.mark.parametrize("B,C,dims,relu,skip", [(1, 32, (4, 6, 10), True, False), (2, 64, (3, 5, 7), True, True),
                                                 (1, 32, (8, 8, 8), False, True), (2, 32, (2, 3, 5), False, False),

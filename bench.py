@@ -132,7 +132,6 @@ def main():
         note(f"warmup step {i + 1}/{args.warmup} done")
     # time EXACTLY K steps; the dominant kernels are also event-timed per launch on the launch stream
     lib.enable_timer("ecm_conv3d_k3_fwd")
-    lib.enable_timer("ecm_costvol_right_fwd")       # in the model only the target-image half of the volume is built
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -150,7 +149,7 @@ def main():
         h, w, Dl = H // 4, W // 4, D // 4
         # "ms per cost-volume build" (BASELINE.json's second metric) is the stand-alone build of the reference's full
         # [B,2C,D',h,w] concat volume (ops.cost_volume = cmfsm.py:667-682), timed here on features of the bench's shape;
-        # inside the model the reference-image half is never materialised (ops.costvol_conv3d), see DESIGN.md.
+        # inside the model the volume is never materialised: its convolution collapses to 2-D ones (ops.costvol_conv3d).
         fl, fr = (torch.randn(B, 32, h, w, device=dev) for _ in range(2))
         for _ in range(3):
             ecm_amd.ops.cost_volume(fl, fr, Dl)
@@ -198,8 +197,6 @@ def main():
                                    f"{'fwd+bwd+Adam (train.py path)' if args.mode == 'train' else 'eval forward (test.py path)'}",
                        "arch": "cmfsm", "global_batch": B * world, "parallelism": f"dp{world}"},
             "ms_per_cost_volume": cv_ms / B,
-            "ms_per_cost_volume_in_model": (sum(s_.elapsed_time(e_) for s_, e_, _ in timers.get("ecm_costvol_right_fwd", []))
-                                            / max(1, len(timers.get("ecm_costvol_right_fwd", []))) / B),
             "roofline": {"kernel": "conv3d_k3_mfma<1,1,4,8,4> (all stride-1, Co<=32 launches: fwd + dgrad)", "bound": "mfma",
                          "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_conv,

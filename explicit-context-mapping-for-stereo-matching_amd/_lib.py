@@ -50,10 +50,8 @@ PROTOTYPES = {
     "ecm_stereo_loss_scratch_bytes": (_LL, [_LL]),
     "ecm_stereo_loss_fwd": (_I, [_P] * 6 + [_LL, _LL, _F, _F, _F, _F, _P]),
     "ecm_stereo_loss_bwd": (_I, [_P] * 9 + [_LL, _F, _F, _F, _F, _P]),
-    "ecm_costvol_right_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "ecm_costvol_right_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "ecm_costvol_class_add_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "ecm_costvol_class_add_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ecm_costvol_conv_assemble_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ecm_costvol_conv_assemble_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ecm_gn3d_scratch_bytes": (_LL, [_I, _I, _LL]),
     "ecm_gn3d_stats": (_I, [_P, _P, _P, _LL, _I, _I, _LL, _F, _P]),
     "ecm_gn3d_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _LL, _I, _P]),

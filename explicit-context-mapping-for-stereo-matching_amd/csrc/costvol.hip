@@ -24,9 +24,7 @@ __device__ __forceinline__ float4 shift_combine(const float4& lo, const float4& 
     }
 }
 
-// RIGHT_ONLY: only the shifted target-image half is produced, as [B,C,D,h,w] -- the reference-image half is
-// constant along d where it is not zero, so its convolution never needs the 4-D tensor (ops.costvol_conv3d).
-template <int R, bool RIGHT_ONLY>
+template <int R>
 __device__ __forceinline__ void emit_one(float* __restrict__ outL, float* __restrict__ outR, size_t plane,
                                          int d, int x, const float4& Lv, const float4& lo, const float4& hi, int D) {
     if (d >= D) return;
@@ -35,12 +33,11 @@ __device__ __forceinline__ void emit_one(float* __restrict__ outL, float* __rest
     if (x + 1 < d) { l.y = 0.f; r.y = 0.f; }
     if (x + 2 < d) { l.z = 0.f; r.z = 0.f; }
     if (x + 3 < d) { l.w = 0.f; r.w = 0.f; }
-    if (!RIGHT_ONLY) *reinterpret_cast<float4*>(outL + (size_t)d * plane) = l;
+    *reinterpret_cast<float4*>(outL + (size_t)d * plane) = l;
     *reinterpret_cast<float4*>(outR + (size_t)d * plane) = r;
 }
 
 // w % 4 == 0 (so a float4 never straddles a row) and hw % 4 == 0.
-template <bool RIGHT_ONLY>
 __global__ __launch_bounds__(THREADS) void costvol_fwd_v4(const float* __restrict__ L, const float* __restrict__ R,
                                                           float* __restrict__ cost, int C, int hw, int w, int D,
                                                           int dpad) {
@@ -61,25 +58,24 @@ __global__ __launch_bounds__(THREADS) void costvol_fwd_v4(const float* __restric
     const int f = f0 + threadIdx.x * 4;
     if (f >= hw) return;
     const int x = f % w;
-    const float4 Lv = RIGHT_ONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(Lp + f);
+    const float4 Lv = *reinterpret_cast<const float4*>(Lp + f);
     const size_t plane = (size_t)hw;
     float* outL = cost + ((size_t)(b * 2 * C + c) * D) * plane + f;
-    float* outR = RIGHT_ONLY ? cost + ((size_t)bc * D) * plane + f : cost + ((size_t)(b * 2 * C + C + c) * D) * plane + f;
+    float* outR = cost + ((size_t)(b * 2 * C + C + c) * D) * plane + f;
     const float4* Rs4 = reinterpret_cast<const float4*>(Rs) + dpad / 4 + threadIdx.x;   // block holding x..x+3
     float4 hi = Rs4[0];
     for (int q = 0; 4 * q < D; ++q) {
         const float4 lo = Rs4[-(q + 1)];       // x-4q-4 .. x-4q-1  (index >= 0 because dpad >= D+3 rounded)
         const int d = 4 * q;
-        emit_one<0, RIGHT_ONLY>(outL, outR, plane, d + 0, x, Lv, lo, hi, D);
-        emit_one<1, RIGHT_ONLY>(outL, outR, plane, d + 1, x, Lv, lo, hi, D);
-        emit_one<2, RIGHT_ONLY>(outL, outR, plane, d + 2, x, Lv, lo, hi, D);
-        emit_one<3, RIGHT_ONLY>(outL, outR, plane, d + 3, x, Lv, lo, hi, D);
+        emit_one<0>(outL, outR, plane, d + 0, x, Lv, lo, hi, D);
+        emit_one<1>(outL, outR, plane, d + 1, x, Lv, lo, hi, D);
+        emit_one<2>(outL, outR, plane, d + 2, x, Lv, lo, hi, D);
+        emit_one<3>(outL, outR, plane, d + 3, x, Lv, lo, hi, D);
         hi = lo;
     }
 }
 
 // Generic scalar fallback (any w): one thread per (b, c2, y, x), loops over d.
-template <bool RIGHT_ONLY>
 __global__ void costvol_fwd_scalar(const float* __restrict__ L, const float* __restrict__ R, float* __restrict__ cost,
                                    int C, int hw, int w, int D, long long total) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,13 +84,13 @@ __global__ void costvol_fwd_scalar(const float* __restrict__ L, const float* __r
     int bc = (int)(i / hw);
     int b = bc / C, c = bc - b * C;
     int x = f % w;
-    float lv = RIGHT_ONLY ? 0.f : L[i], rv;
+    float lv = L[i], rv;
     float* outL = cost + ((size_t)(b * 2 * C + c) * D) * hw + f;
-    float* outR = RIGHT_ONLY ? cost + ((size_t)bc * D) * hw + f : cost + ((size_t)(b * 2 * C + C + c) * D) * hw + f;
+    float* outR = cost + ((size_t)(b * 2 * C + C + c) * D) * hw + f;
     for (int d = 0; d < D; ++d) {
         bool ok = x >= d;
         rv = ok ? R[i - d] : 0.f;
-        if (!RIGHT_ONLY) outL[(size_t)d * hw] = ok ? lv : 0.f;
+        outL[(size_t)d * hw] = ok ? lv : 0.f;
         outR[(size_t)d * hw] = rv;
     }
 }
@@ -104,18 +100,16 @@ __global__ void costvol_fwd_scalar(const float* __restrict__ L, const float* __r
 // Thread owns the float4 at flat f (x..x+3) of one (b,c) plane.  The diagonal gather for gR uses
 // two ALIGNED float4 loads per disparity (x+4q and x+4q+4; the second is the neighbour lane's first
 // and hits L1), recombined with the wave-uniform r = d%4.
-template <int R, bool RIGHT_ONLY>
+template <int R>
 __device__ __forceinline__ void acc_one(const float* __restrict__ gLp, const float* __restrict__ gRp, size_t plane,
                                         int d, int x, int w, int D, float4& aL, float4& aR, const float4& lo,
                                         const float4& hi) {
     if (d >= D) return;
-    if (!RIGHT_ONLY) {
-        const float4 g = *reinterpret_cast<const float4*>(gLp + (size_t)d * plane);
-        if (x + 0 >= d) aL.x += g.x;
-        if (x + 1 >= d) aL.y += g.y;
-        if (x + 2 >= d) aL.z += g.z;
-        if (x + 3 >= d) aL.w += g.w;
-    }
+    const float4 g = *reinterpret_cast<const float4*>(gLp + (size_t)d * plane);
+    if (x + 0 >= d) aL.x += g.x;
+    if (x + 1 >= d) aL.y += g.y;
+    if (x + 2 >= d) aL.z += g.z;
+    if (x + 3 >= d) aL.w += g.w;
     // elements x+d .. x+d+3 of the gR row = elements [R .. R+3] of {lo (x+4q..), hi (x+4q+4..)}
     float4 v;
     switch (R) {
@@ -135,7 +129,6 @@ __device__ __forceinline__ float4 ld4_row(const float* p, int x, int w) {   // z
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <bool RIGHT_ONLY>
 __global__ __launch_bounds__(THREADS) void costvol_bwd_v4(const float* __restrict__ gcost, float* __restrict__ gL,
                                                           float* __restrict__ gR, int C, int hw, int w, int D) {
     const int bc = blockIdx.y;
@@ -145,7 +138,7 @@ __global__ __launch_bounds__(THREADS) void costvol_bwd_v4(const float* __restric
     const int x = f % w;
     const size_t plane = (size_t)hw;
     const float* gLp = gcost + ((size_t)(b * 2 * C + c) * D) * plane + f;
-    const float* gRp = RIGHT_ONLY ? gcost + ((size_t)bc * D) * plane + f : gcost + ((size_t)(b * 2 * C + C + c) * D) * plane + f;
+    const float* gRp = gcost + ((size_t)(b * 2 * C + C + c) * D) * plane + f;
     float4 aL = make_float4(0.f, 0.f, 0.f, 0.f), aR = aL;
     for (int q = 0; 4 * q < D; ++q) {
         const int d = 4 * q;
@@ -155,16 +148,15 @@ __global__ __launch_bounds__(THREADS) void costvol_bwd_v4(const float* __restric
             const float* p = gRp + (size_t)(d + RR) * plane + 4 * q;                                     \
             const float4 lo = ld4_row(p, x + 4 * q, w);                                                  \
             const float4 hi = ld4_row(p + 4, x + 4 * q + 4, w);                                          \
-            acc_one<RR, RIGHT_ONLY>(gLp, gRp, plane, d + RR, x, w, D, aL, aR, lo, hi);                               \
+            acc_one<RR>(gLp, gRp, plane, d + RR, x, w, D, aL, aR, lo, hi);                               \
         }
         ECM_STEP(0) ECM_STEP(1) ECM_STEP(2) ECM_STEP(3)
 #undef ECM_STEP
     }
-    if (!RIGHT_ONLY) *reinterpret_cast<float4*>(gL + (size_t)bc * hw + f) = aL;
+    *reinterpret_cast<float4*>(gL + (size_t)bc * hw + f) = aL;
     *reinterpret_cast<float4*>(gR + (size_t)bc * hw + f) = aR;
 }
 
-template <bool RIGHT_ONLY>
 __global__ void costvol_bwd_scalar(const float* __restrict__ gcost, float* __restrict__ gL, float* __restrict__ gR,
                                    int C, int hw, int w, int D, long long total) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,46 +166,14 @@ __global__ void costvol_bwd_scalar(const float* __restrict__ gcost, float* __res
     int b = bc / C, c = bc - b * C;
     int x = f % w;
     const float* gLp = gcost + ((size_t)(b * 2 * C + c) * D) * hw + f;
-    const float* gRp = RIGHT_ONLY ? gcost + ((size_t)bc * D) * hw + f : gcost + ((size_t)(b * 2 * C + C + c) * D) * hw + f;
+    const float* gRp = gcost + ((size_t)(b * 2 * C + C + c) * D) * hw + f;
     float aL = 0.f, aR = 0.f;
     for (int d = 0; d < D; ++d) {
-        if (!RIGHT_ONLY && x >= d) aL += gLp[(size_t)d * hw];
+        if (x >= d) aL += gLp[(size_t)d * hw];
         if (x + d < w) aR += gRp[(size_t)d * hw + d];
     }
-    if (!RIGHT_ONLY) gL[i] = aL;
+    gL[i] = aL;
     gR[i] = aR;
-}
-
-
-
-template <bool RIGHT_ONLY>
-int launch_costvol_fwd(const float* L, const float* R, float* cost, int B, int C, int h, int w, int D, hipStream_t st) {
-    const int hw = h * w;
-    if (w % 4 == 0 && (long long)B * C <= 65535) {
-        const int dpad = ((D + 3) / 4 + 1) * 4;
-        dim3 grid((hw + SEG - 1) / SEG, B * C);
-        hipLaunchKernelGGL(costvol_fwd_v4<RIGHT_ONLY>, grid, dim3(THREADS), (dpad + SEG) * sizeof(float), st, L, R, cost, C,
-                           hw, w, D, dpad);
-    } else {
-        long long total = (long long)B * C * hw;
-        hipLaunchKernelGGL(costvol_fwd_scalar<RIGHT_ONLY>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, L, R, cost,
-                           C, hw, w, D, total);
-    }
-    return ECM_LAUNCH_RESULT();
-}
-
-template <bool RIGHT_ONLY>
-int launch_costvol_bwd(const float* gcost, float* gL, float* gR, int B, int C, int h, int w, int D, hipStream_t st) {
-    const int hw = h * w;
-    if (w % 4 == 0 && (long long)B * C <= 65535) {
-        dim3 grid((hw + SEG - 1) / SEG, B * C);
-        hipLaunchKernelGGL(costvol_bwd_v4<RIGHT_ONLY>, grid, dim3(THREADS), 0, st, gcost, gL, gR, C, hw, w, D);
-    } else {
-        long long total = (long long)B * C * hw;
-        hipLaunchKernelGGL(costvol_bwd_scalar<RIGHT_ONLY>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gcost, gL,
-                           gR, C, hw, w, D, total);
-    }
-    return ECM_LAUNCH_RESULT();
 }
 
 }  // namespace
@@ -221,21 +181,31 @@ int launch_costvol_bwd(const float* gcost, float* gL, float* gR, int B, int C, i
 extern "C" int ecm_costvol_concat_fwd(const float* L, const float* R, float* cost, int B, int C, int h, int w, int D,
                                       void* stream) {
     ECM_CHECK_ARG(L && R && cost && B > 0 && C > 0 && h > 0 && w > 0 && D > 0);
-    return launch_costvol_fwd<false>(L, R, cost, B, C, h, w, D, ecm_stream(stream));
+    const int hw = h * w;
+    if (w % 4 == 0 && (long long)B * C <= 65535) {
+        const int dpad = ((D + 3) / 4 + 1) * 4;
+        dim3 grid((hw + SEG - 1) / SEG, B * C);
+        hipLaunchKernelGGL(costvol_fwd_v4, grid, dim3(THREADS), (dpad + SEG) * sizeof(float), ecm_stream(stream), L, R,
+                           cost, C, hw, w, D, dpad);
+    } else {
+        long long total = (long long)B * C * hw;
+        hipLaunchKernelGGL(costvol_fwd_scalar, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ecm_stream(stream),
+                           L, R, cost, C, hw, w, D, total);
+    }
+    return ECM_LAUNCH_RESULT();
 }
 
 extern "C" int ecm_costvol_concat_bwd(const float* gcost, float* gL, float* gR, int B, int C, int h, int w, int D,
                                       void* stream) {
     ECM_CHECK_ARG(gcost && gL && gR && B > 0 && C > 0 && h > 0 && w > 0 && D > 0);
-    return launch_costvol_bwd<false>(gcost, gL, gR, B, C, h, w, D, ecm_stream(stream));
-}
-
-extern "C" int ecm_costvol_right_fwd(const float* R, float* cost_r, int B, int C, int h, int w, int D, void* stream) {
-    ECM_CHECK_ARG(R && cost_r && B > 0 && C > 0 && h > 0 && w > 0 && D > 0);
-    return launch_costvol_fwd<true>(R, R, cost_r, B, C, h, w, D, ecm_stream(stream));
-}
-
-extern "C" int ecm_costvol_right_bwd(const float* gcost_r, float* gR, int B, int C, int h, int w, int D, void* stream) {
-    ECM_CHECK_ARG(gcost_r && gR && B > 0 && C > 0 && h > 0 && w > 0 && D > 0);
-    return launch_costvol_bwd<true>(gcost_r, gR, gR, B, C, h, w, D, ecm_stream(stream));
+    const int hw = h * w;
+    if (w % 4 == 0 && (long long)B * C <= 65535) {
+        dim3 grid((hw + SEG - 1) / SEG, B * C);
+        hipLaunchKernelGGL(costvol_bwd_v4, grid, dim3(THREADS), 0, ecm_stream(stream), gcost, gL, gR, C, hw, w, D);
+    } else {
+        long long total = (long long)B * C * hw;
+        hipLaunchKernelGGL(costvol_bwd_scalar, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ecm_stream(stream),
+                           gcost, gL, gR, C, hw, w, D, total);
+    }
+    return ECM_LAUNCH_RESULT();
 }

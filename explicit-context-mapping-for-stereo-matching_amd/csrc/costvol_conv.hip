@@ -1,27 +1,34 @@
-// First aggregation conv on the concat cost volume without the reference-image half (cmfsm.py:667-684:
-// `cost[:, :C, i, :, i:] = L[..., i:]` followed by dres0's Conv3d(64, 32, 3, pad 1)).
+// Cost volume + dres0's first Conv3d (cmfsm.py:667-684) WITHOUT the 4-D volume.
 //
-// The reference-image half of the volume is costL[c,d,h,w] = L[c,h,w]*[w >= d]: constant along d where it is not zero.
-// Its contribution to the 3x3x3 convolution at (d,w) therefore depends on d only through which taps pass the wedge
-// test  w+kw-1 >= d+kd-1  <=>  kw-kd >= d-w  and the depth-padding test 0 <= d+kd-1 < D, i.e. through
-//     class(d,w) = (clamp(d-w, -2, 2), first / interior / last d)              (15 classes; d-w >= 3: no tap passes)
-// and equals P[class][co,h,w] = conv2d(L, sum_{kd passing} W[:, :C, kd])[co,h,w].  So
-//     conv3d(cost, W) = conv3d(costR, W[:, C:]) + P[class(d,w)]
-// costs a 32->32 3-D conv + fifteen 32->32 2-D convs on the feature map instead of a 64->32 3-D conv, and the
-// reference-image half of the 4-D volume is never written or read.  These kernels do the class gather (forward, in
-// place on the 3-D conv output) and its adjoint (backward: sums of gy over the d of each class).  Needs D >= 2.
+// The concat volume has two halves that are both constant along a line in (d, x):
+//   reference half   costL[c,d,y,x] = L[c,y,x]   * [x >= d]        constant along d
+//   target half      costR[c,d,y,x] = R[c,y,x-d] * [x >= d]        constant along d at fixed u = x - d
+// so a 3x3x3 convolution over them collapses to 2-D convolutions of the feature maps:
+//   reference half:  tap (kd,kh,kw) reads L[y+kh-1, x+kw-1] if kw-kd >= d-x (wedge at the tap) and 0 <= d+kd-1 < D;
+//                    the set of passing kd depends on (d,x) only through
+//                        classP(d,x) = (clamp(d-x,-2,2), first/interior/last d)            15 classes, d-x >= 3: none
+//                    => contribution P[classP][co,y,x],  P[c] = conv2d_3x3(L, sum_{kd passing} W[:, :C, kd]).
+//   target half:     tap (kd,kh,kw) reads R[y+kh-1, (x-d) + (kw-kd)]: a 3x5 kernel over (kh, ku = kw-kd) evaluated at
+//                    u = x-d, with taps dropped when d+kd-1 is outside [0,D) or x+kw-1 == w (right border); zero for
+//                    u+ku < 0 is the wedge.  classQ(d,x) = (first/interior/last d, x == w-1)         6 classes
+//                    => contribution Q[classQ][co,y,u],  Q[c] = conv2d_3x5(R, sum_{kd,kw: kw-kd=ku, passing} W[:, C:]).
+//   y[b,co,d,y,x] = P[b,classP(d,x),co,y,x] + Q[b,classQ(d,x),co,y,x-d]           (x-d >= -2; below that y = 0)
+// The 2-D convolutions (32 -> 15*32 and 32 -> 6*32 channels on the 1/4-resolution map, ~16 GFLOP per pair instead of the
+// 183 GFLOP of the 64->32 3-D convolution) run in the host layer; these kernels assemble the output volume and, in
+// backward, reduce gy over d into gP / gQ (the adjoint of the assembly).  Q is stored with a 2-column left apron:
+// Qp[..., j] = Q[..., u = j - 2], j in [0, w+2).  Needs D >= 2.
 #include "common.h"
 
 namespace {
 
-constexpr int NCLS = 15;
+constexpr int NCP = 15, NCQ = 6;
 
 __device__ __forceinline__ int edge_of(int d, int D) { return d == 0 ? 0 : (d == D - 1 ? 2 : 1); }
 
-// y[b,co,d,h,w] += P[b,cls(d,w),co,h,w]      y: [B,Co,D,h,w] in place;  P: [B,15,Co,h,w]
 template <bool VEC4>
-__global__ __launch_bounds__(256) void class_gather_add(float* __restrict__ y, const float* __restrict__ P, int Co, int D,
-                                                        int h, int w, long long nvec) {
+__global__ __launch_bounds__(256) void costvol_conv_assemble(const float* __restrict__ P, const float* __restrict__ Qp,
+                                                             float* __restrict__ y, int Co, int D, int h, int w,
+                                                             long long nvec) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= nvec) return;
     constexpr int V = VEC4 ? 4 : 1;
@@ -32,29 +39,28 @@ __global__ __launch_bounds__(256) void class_gather_add(float* __restrict__ y, c
     const int d = (int)(r % D); r /= D;
     const int co = (int)(r % Co);
     const int b = (int)(r / Co);
-    if (d - (x0 + V - 1) >= 3) return;                       // every lane element is deep in the wedge: nothing to add
     const int e = edge_of(d, D);
-    const size_t hw = (size_t)h * w;
-    const float* Pb = P + (((size_t)b * NCLS) * Co + co) * hw + (size_t)yy * w;
-    float* yp = y + i * V;
+    const size_t hw = (size_t)h * w, hq = (size_t)h * (w + 2);
+    const float* Pb = P + (((size_t)b * NCP) * Co + co) * hw + (size_t)yy * w;
+    const float* Qb = Qp + (((size_t)b * NCQ) * Co + co) * hq + (size_t)yy * (w + 2);
     float v[V];
-    if (VEC4) { const float4 t = *reinterpret_cast<const float4*>(yp); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-    else v[0] = *yp;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const int x = x0 + k, delta = d - x;
+        float acc = 0.f;
         if (delta < 3) {
             const int dc = (delta < -2 ? -2 : delta) + 2;
-            v[k] += Pb[(size_t)(dc * 3 + e) * Co * hw + x];
+            acc = Pb[(size_t)(dc * 3 + e) * Co * hw + x] + Qb[(size_t)(e * 2 + (x == w - 1 ? 1 : 0)) * Co * hq + (x - d + 2)];
         }
+        v[k] = acc;
     }
-    if (VEC4) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-    else *yp = v[0];
+    if (VEC4) *reinterpret_cast<float4*>(y + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    else y[i] = v[0];
 }
 
-// gP[b,cls,co,h,w] = sum over d with cls(d,w) == cls of gy[b,co,d,h,w]      (one thread per (b,co,h,w), w fastest)
-__global__ __launch_bounds__(256) void class_gather_bwd(const float* __restrict__ gy, float* __restrict__ gP, int Co, int D,
-                                                        int h, int w, long long total) {
+// gP[b,cls,co,y,x] = sum over d with classP(d,x) == cls of gy[b,co,d,y,x]      (one thread per (b,co,y,x), x fastest)
+__global__ __launch_bounds__(256) void costvol_conv_gp(const float* __restrict__ gy, float* __restrict__ gP, int Co, int D,
+                                                       int h, int w, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int x = (int)(i % w);
@@ -64,9 +70,9 @@ __global__ __launch_bounds__(256) void class_gather_bwd(const float* __restrict_
     const int b = (int)(r / Co);
     const size_t hw = (size_t)h * w;
     const float* g = gy + (((size_t)b * Co + co) * D) * hw + (size_t)yy * w + x;
-    float out[NCLS];
+    float out[NCP];
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) out[c] = 0.f;
+    for (int c = 0; c < NCP; ++c) out[c] = 0.f;
     // d - x <= -2: every tap passes the wedge test; split by depth edge
     const int da = x - 2 < D - 1 ? x - 2 : D - 1;           // last d of this region
     if (da >= 0) out[0] = g[0];
@@ -89,32 +95,70 @@ __global__ __launch_bounds__(256) void class_gather_bwd(const float* __restrict_
             out[k * 3 + 2] = e == 2 ? v : 0.f;
         }
     }
-    float* o = gP + (((size_t)b * NCLS) * Co + co) * hw + (size_t)yy * w + x;
+    float* o = gP + (((size_t)b * NCP) * Co + co) * hw + (size_t)yy * w + x;
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) o[(size_t)c * Co * hw] = out[c];
+    for (int c = 0; c < NCP; ++c) o[(size_t)c * Co * hw] = out[c];
+}
+
+// gQp[b,cls,co,y,j] = sum over d with x = (j-2)+d in [0,w) and classQ(d,x) == cls of gy[b,co,d,y,x]
+// (one thread per (b,co,y,j), j fastest: for a fixed d consecutive lanes read consecutive x)
+__global__ __launch_bounds__(256) void costvol_conv_gq(const float* __restrict__ gy, float* __restrict__ gQp, int Co, int D,
+                                                       int h, int w, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int wq = w + 2;
+    const int j = (int)(i % wq);
+    long long r = i / wq;
+    const int yy = (int)(r % h); r /= h;
+    const int co = (int)(r % Co);
+    const int b = (int)(r / Co);
+    const size_t hw = (size_t)h * w;
+    const float* g = gy + (((size_t)b * Co + co) * D) * hw + (size_t)yy * w;
+    const int u = j - 2;
+    float first = 0.f, mid = 0.f, last = 0.f, firstr = 0.f, midr = 0.f, lastr = 0.f;      // (edge, right-border) sums
+    const int d0 = u < 0 ? -u : 0;                          // x = u + d >= 0
+    const int d1 = w - 1 - u < D - 1 ? w - 1 - u : D - 1;   // x <= w - 1
+    for (int d = d0; d <= d1; ++d) {
+        const int x = u + d;
+        const float v = g[(size_t)d * hw + x];
+        const bool rb = x == w - 1;
+        if (d == 0) { if (rb) firstr += v; else first += v; }
+        else if (d == D - 1) { if (rb) lastr += v; else last += v; }
+        else { if (rb) midr += v; else mid += v; }
+    }
+    const size_t hq = (size_t)h * wq;
+    float* o = gQp + (((size_t)b * NCQ) * Co + co) * hq + (size_t)yy * wq + j;
+    o[0 * Co * hq] = first; o[1 * Co * hq] = firstr;
+    o[2 * Co * hq] = mid;   o[3 * Co * hq] = midr;
+    o[4 * Co * hq] = last;  o[5 * Co * hq] = lastr;
 }
 
 }  // namespace
 
-extern "C" int ecm_costvol_class_add_fwd(float* y, const float* P, int B, int Co, int D, int h, int w, void* stream) {
-    ECM_CHECK_ARG(y && P && B > 0 && Co > 0 && h > 0 && w > 0);
+extern "C" int ecm_costvol_conv_assemble_fwd(const float* P, const float* Qp, float* y, int B, int Co, int D, int h, int w,
+                                             void* stream) {
+    ECM_CHECK_ARG(P && Qp && y && B > 0 && Co > 0 && h > 0 && w > 0);
     if (D < 2) return ECM_EUNSUP;
     const long long n = (long long)B * Co * D * h * w;
     hipStream_t st = ecm_stream(stream);
     if (w % 4 == 0) {
         const long long nv = n / 4;
-        hipLaunchKernelGGL(class_gather_add<true>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, y, P, Co, D, h, w, nv);
+        hipLaunchKernelGGL(costvol_conv_assemble<true>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, P, Qp, y, Co, D, h,
+                           w, nv);
     } else {
-        hipLaunchKernelGGL(class_gather_add<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, P, Co, D, h, w, n);
+        hipLaunchKernelGGL(costvol_conv_assemble<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, Qp, y, Co, D, h,
+                           w, n);
     }
     return ECM_LAUNCH_RESULT();
 }
 
-extern "C" int ecm_costvol_class_add_bwd(const float* gy, float* gP, int B, int Co, int D, int h, int w, void* stream) {
-    ECM_CHECK_ARG(gy && gP && B > 0 && Co > 0 && h > 0 && w > 0);
+extern "C" int ecm_costvol_conv_assemble_bwd(const float* gy, float* gP, float* gQp, int B, int Co, int D, int h, int w,
+                                             void* stream) {
+    ECM_CHECK_ARG(gy && gP && gQp && B > 0 && Co > 0 && h > 0 && w > 0);
     if (D < 2) return ECM_EUNSUP;
-    const long long total = (long long)B * Co * h * w;
-    hipLaunchKernelGGL(class_gather_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ecm_stream(stream), gy, gP, Co,
-                       D, h, w, total);
+    hipStream_t st = ecm_stream(stream);
+    const long long tp = (long long)B * Co * h * w, tq = (long long)B * Co * h * (w + 2);
+    hipLaunchKernelGGL(costvol_conv_gp, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, st, gy, gP, Co, D, h, w, tp);
+    hipLaunchKernelGGL(costvol_conv_gq, dim3((unsigned)((tq + 255) / 256)), dim3(256), 0, st, gy, gQp, Co, D, h, w, tq);
     return ECM_LAUNCH_RESULT();
 }

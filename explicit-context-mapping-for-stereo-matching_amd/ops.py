@@ -81,88 +81,75 @@ def cost_volume(left, right, ndisp):
     return CostVolumeConcat.apply(left, right, int(ndisp))
 
 
-class CostVolumeRight(torch.autograd.Function):
-    """Target-image half of the cost volume only (cmfsm.py:678-681): R [B,C,h,w] -> [B,C,D,h,w]."""
+class CostvolConvAssemble(torch.autograd.Function):
+    """y[b,co,d,h,x] = P[b,classP(d,x),co,h,x] + Qp[b,classQ(d,x),co,h,x-d+2] (see csrc/costvol_conv.hip);
+    backward: gP, gQp = per-class sums of gy over d."""
 
     @staticmethod
-    def forward(ctx, right, ndisp):
-        _chk(right)
-        right = _c(right)
-        B, Cc, h, w = right.shape
-        cost = torch.empty(B, Cc, ndisp, h, w, device=right.device, dtype=right.dtype)
-        _lib.call("ecm_costvol_right_fwd", _p(right), _p(cost), B, Cc, h, w, ndisp, _stream())
-        ctx.dims = (B, Cc, h, w, ndisp)
-        return cost
-
-    @staticmethod
-    def backward(ctx, gcost):
-        B, Cc, h, w, D = ctx.dims
-        gcost = _c(gcost)
-        gr = torch.empty(B, Cc, h, w, device=gcost.device, dtype=gcost.dtype)
-        _lib.call("ecm_costvol_right_bwd", _p(gcost), _p(gr), B, Cc, h, w, D, _stream())
-        return gr, None
-
-
-class CostvolClassAdd(torch.autograd.Function):
-    """y[b,co,d,h,w] += P[b,class(d,w),co,h,w] in place (see csrc/costvol_conv.hip); backward: gy passes through,
-    gP = per-class sums of gy over d."""
-
-    @staticmethod
-    def forward(ctx, y, P):
-        _chk(y, P)
-        B, Co, D, h, w = y.shape
-        if not (y.is_contiguous() and y.data_ptr() % 16 == 0):
-            raise RuntimeError("costvol class add works in place on a contiguous, 16-byte aligned conv output")
-        P = _c(P)
-        assert P.shape == (B, 15 * Co, h, w), (P.shape, y.shape)
-        _lib.call("ecm_costvol_class_add_fwd", _p(y), _p(P), B, Co, D, h, w, _stream())
-        ctx.mark_dirty(y)
-        ctx.dims = (B, Co, D, h, w)
+    def forward(ctx, P, Qp, ndisp):
+        _chk(P, Qp)
+        P, Qp = _c(P), _c(Qp)
+        B, c15, h, w = P.shape
+        Co = c15 // 15
+        assert c15 == 15 * Co and Qp.shape == (B, 6 * Co, h, w + 2), (P.shape, Qp.shape)
+        y = torch.empty(B, Co, ndisp, h, w, device=P.device, dtype=P.dtype)
+        _lib.call("ecm_costvol_conv_assemble_fwd", _p(P), _p(Qp), _p(y), B, Co, ndisp, h, w, _stream())
+        ctx.dims = (B, Co, ndisp, h, w)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         B, Co, D, h, w = ctx.dims
-        gyc = _c(gy)
+        gy = _c(gy)
         gP = torch.empty(B, 15 * Co, h, w, device=gy.device, dtype=gy.dtype)
-        _lib.call("ecm_costvol_class_add_bwd", _p(gyc), _p(gP), B, Co, D, h, w, _stream())
-        return gy, gP
+        gQ = torch.empty(B, 6 * Co, h, w + 2, device=gy.device, dtype=gy.dtype)
+        _lib.call("ecm_costvol_conv_assemble_bwd", _p(gy), _p(gP), _p(gQ), B, Co, D, h, w, _stream())
+        return gP, gQ, None
 
 
 _CLASS_TAPS = {}
 
 
-def _class_tap_mask(device):
-    """[15, kd, kw] 0/1: which depth taps of the reference-image half pass, per class = (clamp(d-w,-2,2)+2)*3 + edge,
-    edge 0/1/2 = first / interior / last disparity plane.  A tap passes iff kw-kd >= d-w (wedge `x >= d` of
-    cmfsm.py:678-679 at the tap's position) and 0 <= d+kd-1 < D (depth padding)."""
+def _class_tap_masks(device):
+    """0/1 tap-selection tensors of the two halves of the concat volume (csrc/costvol_conv.hip):
+    mP [15, kd, kw]      reference half: class = (clamp(d-x,-2,2)+2)*3 + edge; a tap passes iff kw-kd >= d-x (the wedge
+                         `x >= d` of cmfsm.py:678-679 at the tap's position) and 0 <= d+kd-1 < D (depth padding);
+    mQ [6, kd, kw, ku]   target half: class = edge*2 + (x == w-1); a passing tap (depth padding; kw != 2 on the right
+                         border) lands on column ku = kw-kd+2 of the sheared 3x5 kernel.
+    edge = 0 / 1 / 2 for the first / an interior / the last disparity plane."""
     m = _CLASS_TAPS.get(device)
     if m is None:
-        m = torch.zeros(15, 3, 3)
-        for dc in range(5):
-            for e in range(3):
-                for kd in range(3):
-                    if (e == 0 and kd == 0) or (e == 2 and kd == 2):
-                        continue
-                    for kw in range(3):
+        mP, mQ = torch.zeros(15, 3, 3), torch.zeros(6, 3, 3, 5)
+        for e in range(3):
+            for kd in range(3):
+                if (e == 0 and kd == 0) or (e == 2 and kd == 2):
+                    continue
+                for kw in range(3):
+                    for dc in range(5):
                         if kw - kd >= dc - 2:
-                            m[dc * 3 + e, kd, kw] = 1.0
-        m = _CLASS_TAPS[device] = m.to(device)
+                            mP[dc * 3 + e, kd, kw] = 1.0
+                    mQ[e * 2 + 0, kd, kw, kw - kd + 2] = 1.0
+                    if kw != 2:
+                        mQ[e * 2 + 1, kd, kw, kw - kd + 2] = 1.0
+        m = _CLASS_TAPS[device] = (mP.to(device), mQ.to(device))
     return m
 
 
 def costvol_conv3d(left, right, weight, ndisp):
-    """conv3d(cost_volume(left, right, ndisp), weight, stride 1, pad 1)  (cmfsm.py:667-684) WITHOUT the reference-image
-    half of the volume: that half is constant along d where it is not zero, so its contribution is one of fifteen 2-D
-    convolutions of `left`, selected per (d, x) -- see csrc/costvol_conv.hip.  weight: [Co, 2C, 3, 3, 3]."""
+    """conv3d(cost_volume(left, right, ndisp), weight, stride 1, pad 1)  (cmfsm.py:667-684) WITHOUT the 4-D volume: both
+    halves of the concat volume are constant along a line in (d, x), so the 3x3x3 convolution collapses to class-indexed
+    2-D convolutions of the two feature maps (3x3 on `left`, sheared 3x5 on `right`) -- see csrc/costvol_conv.hip.
+    weight: [Co, 2C, 3, 3, 3] (the reference's dres0[0][0].weight)."""
     Cc = left.shape[1]
-    if weight.shape[1] != 2 * Cc or ndisp < 2 or Cc % 32 != 0:
+    if weight.shape[1] != 2 * Cc or ndisp < 2:
         return conv3d_k3(cost_volume(left, right, ndisp), weight, 1)
     Co = weight.shape[0]
-    y = conv3d_k3(CostVolumeRight.apply(right, int(ndisp)), weight[:, Cc:].contiguous(), 1)
-    wst = torch.einsum("xdk,oidhk->xoihk", _class_tap_mask(weight.device), weight[:, :Cc])      # [15,Co,C,3,3]
-    P = conv2d_k3(left, wst.reshape(15 * Co, Cc, 3, 3))                                           # [B,15*Co,h,w]
-    return CostvolClassAdd.apply(y, P)
+    mP, mQ = _class_tap_masks(weight.device)
+    wP = torch.einsum("xdk,oidhk->xoihk", mP, weight[:, :Cc]).reshape(15 * Co, Cc, 3, 3)
+    wQ = torch.einsum("xdkq,oidhk->xoihq", mQ, weight[:, Cc:]).reshape(6 * Co, Cc, 3, 5)
+    P = conv2d_k3(left, wP) if Cc % 32 == 0 else torch.nn.functional.conv2d(left, wP, None, 1, 1)      # [B,15Co,h,w]
+    Qp = torch.nn.functional.conv2d(torch.nn.functional.pad(right, (2, 0)), wQ, None, 1, (1, 2))        # [B,6Co,h,w+2]
+    return CostvolConvAssemble.apply(P, Qp, int(ndisp))
 
 
 # ------------------------------------------------------------------------------------ a8 soft-argmin

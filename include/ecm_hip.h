@@ -171,17 +171,15 @@ int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, con
                  const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
                  long long scratch_bytes, int B, int C, long long S, int relu, void* stream);
 
-/* Target-image half of the cost volume only: cost_r[b,c,d,y,x] = R[b,c,y,x-d] for x >= d, else 0  ([B,C,D,h,w]);
- * bwd: gR[x'] = sum_d gcost_r[d, x'+d].  Used with the class gather below to run dres0's first Conv3d (cmfsm.py:684)
- * without ever materialising the reference-image half (which is constant along d where it is not zero). */
-int ecm_costvol_right_fwd(const float* R, float* cost_r, int B, int C, int h, int w, int D, void* stream);
-int ecm_costvol_right_bwd(const float* gcost_r, float* gR, int B, int C, int h, int w, int D, void* stream);
-/* conv3d(concat volume, W) = conv3d(cost_r, W[:, C:]) + P[class(d,x)], class = (clamp(d-x,-2,2), first/interior/last d)
- * (15 classes; d-x >= 3 adds nothing), P[b,class,co,y,x] = conv2d(L, sum of the W[:, :C, kd] whose taps pass the wedge and
- * depth-padding tests).  fwd: y[B,Co,D,h,w] += P[B,15,Co,h,w][class] in place;  bwd: gP = per-class sums of gy over d.
- * D >= 2. */
-int ecm_costvol_class_add_fwd(float* y, const float* P, int B, int Co, int D, int h, int w, void* stream);
-int ecm_costvol_class_add_bwd(const float* gy, float* gP, int B, int Co, int D, int h, int w, void* stream);
+/* Cost volume + dres0's first Conv3d (cmfsm.py:667-684) without the 4-D volume: both halves of the concat volume are
+ * constant along a line in (d,x), so the 3x3x3 convolution collapses to 2-D convolutions of the feature maps (host side):
+ *   P[b, classP, co, y, x]     classP(d,x) = (clamp(d-x,-2,2)+2)*3 + edge(d)        15 classes, reference-image half
+ *   Qp[b, classQ, co, y, u+2]  classQ(d,x) = edge(d)*2 + (x == w-1), u = x-d         6 classes, target-image half (3x5)
+ *   edge(d) = 0 / 1 / 2 for d == 0 / interior / d == D-1
+ * fwd: y[B,Co,D,h,w] = P[classP(d,x)][x] + Qp[classQ(d,x)][x-d+2] where d-x < 3, else 0.
+ * bwd: gP [B,15,Co,h,w], gQp [B,6,Co,h,w+2] = sums of gy over the d of each class (adjoint of fwd).  D >= 2. */
+int ecm_costvol_conv_assemble_fwd(const float* P, const float* Qp, float* y, int B, int Co, int D, int h, int w, void* stream);
+int ecm_costvol_conv_assemble_bwd(const float* gy, float* gP, float* gQp, int B, int Co, int D, int h, int w, void* stream);
 
 /* Harness loss + metrics (train.py:162,172-174; train_kitti.py:205-216) over n = B*H*W pixels; mask = 0 < gt < maxdisp.
  * out8 (device): [loss, #mask, epe(p3), err3(p3) in %, mean smooth-L1 of p1, p2, p3, 0];

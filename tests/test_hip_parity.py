@@ -168,9 +168,9 @@ def test_ecm_module_tuple(ecm, cmfsm_sd):
 
 
 # ------------------------------------------------------------------ a1 + a5 fused: first conv on the concat volume
-@pytest.mark.parametrize("B,h,w,D", [(1, 8, 16, 6), (2, 6, 36, 12), (1, 5, 9, 2), (1, 4, 12, 20), (1, 8, 64, 48)])
+@pytest.mark.parametrize("B,h,w,D", [(1, 8, 16, 6), (2, 6, 36, 12), (1, 5, 9, 2), (1, 4, 12, 20), (1, 8, 64, 48), (1, 3, 5, 3)])
 def test_costvol_conv3d_split(ecm, B, h, w, D):
-    """conv3d(concat volume) computed without the reference-image half == the plain composition (oracle)."""
+    """conv3d(concat volume) computed as class-indexed 2-D convolutions (no 4-D volume) == the plain composition."""
     L, R = seeded("cvc.L", B, 32, h, w), seeded("cvc.R", B, 32, h, w)
     W = seeded("cvc.W", 32, 64, 3, 3, 3) * (2.0 / (27 * 64)) ** 0.5
     G = seeded("cvc.G", B, 32, D, h, w)
@@ -184,9 +184,6 @@ def test_costvol_conv3d_split(ecm, B, h, w, D):
     close(Lg.grad, Ls.grad, 1e-4, 2e-5)
     close(Rg.grad, Rs.grad, 1e-4, 2e-5)
     close(Wg.grad, Ws.grad, 1e-4, 1e-4 * float(Ws.grad.abs().max()))
-    # the right-half volume itself is a copy: bit-exact
-    cr = ecm.ops.CostVolumeRight.apply(dev(R), D)
-    assert torch.equal(cr.cpu(), O.cost_volume(L, R, D)[:, 32:])
 
 
 # ------------------------------------------------------------------ GroupNorm

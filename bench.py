@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--maxdisp", type=int, default=192)
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--explicit-cost-volume", action="store_true",
+                   help="run the reference's explicit op sequence (4-D concat volume + 64->32 Conv3d) instead of the collapsed 2-D form")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
 
@@ -89,6 +91,8 @@ def main():
     # shape (minutes at this size), so the encoder runs on MIOpen's immediate-mode picks instead.
     torch.backends.cudnn.benchmark = False
 
+    if args.explicit_cost_volume:
+        import_module("explicit-context-mapping-for-stereo-matching_amd.models").EXPLICIT_COST_VOLUME = True
     torch.manual_seed(0)
     model = ecm_amd.get_model("cmfsm").to(dev)
     B, H, W, D = args.batch, args.height, args.width, args.maxdisp
@@ -145,6 +149,25 @@ def main():
         dt = float(t.item())
 
     note(f"timed {args.steps} steps in {dt:.3f} s")
+    # second reading (1 GPU only): the same step with the reference's explicit op sequence -- 4-D concat volume built by
+    # the cost-volume kernel + 64->32 Conv3d on it -- so both forms are on record in the same JSON line
+    explicit = None
+    if world == 1 and not args.explicit_cost_volume:
+        mdl = import_module("explicit-context-mapping-for-stereo-matching_amd.models")
+        mdl.EXPLICIT_COST_VOLUME = True
+        try:
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dte = time.perf_counter() - t1
+            explicit = {"ms_per_step": 1e3 * dte / args.steps, "value": B * args.steps / dte, "unit": "pairs/s",
+                        "note": "same step with ops.cost_volume (explicit [B,2C,D',h,w] tensor) + 64->32 Conv3d"}
+        finally:
+            mdl.EXPLICIT_COST_VOLUME = False
+        note(f"explicit-cost-volume variant: {explicit['ms_per_step']:.1f} ms/step")
     if rank == 0:
         h, w, Dl = H // 4, W // 4, D // 4
         # "ms per cost-volume build" (BASELINE.json's second metric) is the stand-alone build of the reference's full
@@ -195,7 +218,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"SceneFlow {W}x540 (padded to {H}) D={D} batch={B}/GPU "
                                    f"{'fwd+bwd+Adam (train.py path)' if args.mode == 'train' else 'eval forward (test.py path)'}",
-                       "arch": "cmfsm", "global_batch": B * world, "parallelism": f"dp{world}"},
+                       "arch": "cmfsm", "global_batch": B * world, "parallelism": f"dp{world}",
+                       "cost_volume": "explicit 4-D tensor" if args.explicit_cost_volume else "collapsed into 2-D convolutions"},
             "ms_per_cost_volume": cv_ms / B,
             "roofline": {"kernel": "conv3d_k3_mfma<1,1,4,8,4> (all stride-1, Co<=32 launches: fwd + dgrad)", "bound": "mfma",
                          "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -209,6 +233,8 @@ def main():
                                  "unit": "GB/s", "frac": cv_gbs / PEAK_HBM_GBS, "traffic": traffic_cv,
                                  "launches_timed": len(cv), "avg_launch_ms": cv_ms},
         }
+        if explicit is not None:
+            out["explicit_cost_volume"] = explicit
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline (oracle port, 1 pair fwd+bwd at the bench resolution) ...")
             cb = cpu_baseline(args.cpu_threads, H, W)

@@ -24,6 +24,13 @@ from . import ops
 
 NUM_GROUPS = 32  # cmfsm.py:31-33
 
+# True: build the reference's explicit [B,2C,D',h,w] concat volume (ops.cost_volume) and run dres0's first Conv3d on it,
+# exactly the reference's op sequence (cmfsm.py:667-684).  False (default): the same result from class-indexed 2-D
+# convolutions of the feature maps without the 4-D tensor (ops.costvol_conv3d).  Env ECM_EXPLICIT_COST_VOLUME=1 or
+# set `models.EXPLICIT_COST_VOLUME = True`.
+import os as _os
+EXPLICIT_COST_VOLUME = _os.environ.get("ECM_EXPLICIT_COST_VOLUME", "0") == "1"
+
 
 # ------------------------------------------------------------------------------------------------
 # leaf layers: nn.Conv3d / nn.ConvTranspose3d / nn.GroupNorm subclasses so parameter names, shapes and
@@ -119,6 +126,8 @@ def _costvol_dres0(dres0, lr_l, lr_r, ndisp):
     feature map and only the shifted target-image half is materialised (ops.costvol_conv3d).  `ops.cost_volume` is the
     stand-alone builder of the full [B,2C,D,h,w] tensor (kept for the drop-in boundary and the microbench)."""
     conv, gn = dres0[0][0], dres0[0][1]
+    if EXPLICIT_COST_VOLUME:
+        return gn.fused(conv(ops.cost_volume(lr_l, lr_r, ndisp)), None, True)
     return gn.fused(ops.costvol_conv3d(lr_l, lr_r, conv.weight, ndisp), None, True)
 
 

@@ -5,6 +5,8 @@ Tolerances (fp32): cost volume bit-exact; per-stage rtol 1e-4 / atol 1e-5 (reduc
 end-to-end disparity max-abs <= 2e-2 px, mean-abs <= 1e-3 px (the oracle's own 1-vs-8-thread
 noise is 2e-3 px max, fp32-vs-fp64 1.5e-2 px max).
 """
+import importlib
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -362,6 +364,24 @@ def test_full_model_train_step_golden(ecm, cmfsm_sd):
         ref = float(g["gn_" + k.replace(".", "_")])
         got = float(params[k].grad.norm())
         assert abs(got - ref) <= 2e-2 * ref + 1e-7, (k, got, ref)
+
+
+def test_hot_path_explicit_cost_volume_agrees(ecm, cmfsm_sd):
+    """The reference's explicit op sequence (cost-volume kernel + 64->32 Conv3d) and the collapsed 2-D form of the same
+    convolution give the same disparities."""
+    models = importlib.import_module("explicit-context-mapping-for-stereo-matching_amd.models")
+    model = _load_hot(ecm, cmfsm_sd)
+    lr_l, hr_l, lr_r = (dev(seeded(f"g7x.{n}", 1, 32, *s)) for n, s in
+                        (("lr_l", (8, 16)), ("hr_l", (32, 64)), ("lr_r", (8, 16))))
+    with torch.no_grad():
+        a = model.hot_path(lr_l, hr_l, lr_r)
+        models.EXPLICIT_COST_VOLUME = True
+        try:
+            b = model.hot_path(lr_l, hr_l, lr_r)
+        finally:
+            models.EXPLICIT_COST_VOLUME = False
+    for p, q in zip(a, b):
+        close(p, q, 1e-4, 2e-3)
 
 
 def test_hot_path_batch2_q1(ecm, cmfsm_sd):

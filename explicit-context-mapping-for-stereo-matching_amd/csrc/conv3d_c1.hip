@@ -130,7 +130,7 @@ constexpr int GTD = 2, GTH = 8, GTW = 32, GNV = GTD * GTH * GTW;       // 512 vo
 constexpr int GXSTR = GNV + 1;                                           // odd channel stride: 32 lanes (ci) -> 32 banks
 constexpr int GRS = 35, GPS = 361;                                       // gy halo row / plane strides: 3 and 9 (mod 32)
 constexpr int G_GYF = (GTD + 2) * GPS;                                   //   => the 27 tap offsets hit 27 distinct banks
-constexpr int G_LDS_BYTES = (32 * GXSTR + G_GYF + 4 * 1024) * 4;
+constexpr int G_LDS_BYTES = (32 * GXSTR + G_GYF) * 4;                   // 71 KB: two workgroups per CU
 static_assert((GTH + 2) * GRS <= GPS, "plane stride too small");
 
 __global__ __launch_bounds__(256) void conv3d_c1_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [32 ci][GXSTR]
     float* Gs = smem + 32 * GXSTR;          // gy halo tile [(GTD+2)][GPS] (rows of GRS)
-    float* Ps = Gs + G_GYF;                 // [4 waves][1024] end-of-kernel reduction
+    float* Ps = Xs;                         // [4 waves][1024] end-of-kernel reduction, reuses the x image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
     // lane's tap (B operand column) and its offset inside the gy halo tile relative to the voxel's own position
@@ -152,46 +152,69 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const unsigned xplane = (unsigned)DHW * 4u;
-    const long long ntiles = (long long)B * tiles_d * tiles_h * tiles_w;
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        long long r = tile;
-        const int tw = (int)(r % tiles_w); r /= tiles_w;
-        const int th = (int)(r % tiles_h); r /= tiles_h;
-        const int td = (int)(r % tiles_d);
-        const int b = (int)(r / tiles_d);
+    const int ntiles = B * tiles_d * tiles_h * tiles_w;       // < 2^31 (checked by the host)
+    // Register-pipelined staging: the NEXT tile's 64 x values and 6 gy-halo values per thread are requested through
+    // buffer descriptors (out-of-volume positions carry the offset 0x80000000 and read as 0) before this tile's MFMAs,
+    // so a tile costs max(load, MFMA) instead of 10 exposed memory round trips (the first version: 85K cycles per tile).
+    constexpr int NGH = (GTD + 2) * (GTH + 2) * (GTW + 2);                 // gy halo elements
+    constexpr int PG = (NGH + 255) / 256;
+    float xr[64], gr[PG];
+    int gdst[PG];                                                         // tile-invariant LDS slot of each halo element
+#pragma unroll
+    for (int j = 0; j < PG; ++j) {
+        const int e = tid + j * 256;
+        const int xx = e % (GTW + 2), hy = (e / (GTW + 2)) % (GTH + 2), dz = e / ((GTW + 2) * (GTH + 2));
+        gdst[j] = e < NGH ? dz * GPS + hy * GRS + xx : -1;
+    }
+    const int nci = Ci < 32 ? Ci : 32;
+    auto prefetch = [&](unsigned tile) {
+        const bool live = tile < (unsigned)ntiles;
+        unsigned r = live ? tile : 0u;
+        const int tw = (int)(r % (unsigned)tiles_w); r /= (unsigned)tiles_w;
+        const int th = (int)(r % (unsigned)tiles_h); r /= (unsigned)tiles_h;
+        const int td = (int)(r % (unsigned)tiles_d);
+        const int b = (int)(r / (unsigned)tiles_d);
         const int d0 = td * GTD, h0 = th * GTH, w0 = tw * GTW;
-        __syncthreads();
-        // x tile: 32 channels x 512 voxels (2 per thread per channel), zero outside the volume
-        {
-            unsigned off[2];
+        unsigned off[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int v = tid + j * 256;
-                const int xx = v % GTW, hy = (v / GTW) % GTH, dz = v / (GTW * GTH);
-                const int gz = d0 + dz, gyy = h0 + hy, gx = w0 + xx;
-                const bool ok = gz < D && gyy < H && gx < W;
-                off[j] = ok ? (unsigned)(gz * (int)HW + gyy * W + gx) * 4u : 0x80000000u;
-            }
-            const int nci = Ci < 32 ? Ci : 32;
-            const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * Ci * DHW), 0,
-                                                               (unsigned)nci * xplane, 0x00020000);
-#pragma unroll 8
-            for (int cc = 0; cc < 32; ++cc)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    Xs[cc * GXSTR + tid + j * 256] = __builtin_bit_cast(
-                        float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off[j] + (unsigned)cc * xplane, 0, 0));
+        for (int j = 0; j < 2; ++j) {
+            const int v = tid + j * 256;
+            const int xx = v % GTW, hy = (v / GTW) % GTH, dz = v / (GTW * GTH);
+            const int gz = d0 + dz, gyy = h0 + hy, gx = w0 + xx;
+            const bool ok = live && gz < D && gyy < H && gx < W;
+            off[j] = ok ? (unsigned)(gz * (int)HW + gyy * W + gx) * 4u : 0x80000000u;
         }
-        // gy halo tile (GTD+2) x (GTH+2) x (GTW+2), zero outside
-        for (int e = tid; e < (GTD + 2) * (GTH + 2) * (GTW + 2); e += 256) {
+        const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * Ci * DHW), 0,
+                                                           (unsigned)nci * xplane, 0x00020000);
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                xr[cc * 2 + j] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off[j] + (unsigned)cc * xplane, 0, 0));
+        const auto grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy + (size_t)b * DHW), 0, xplane, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < PG; ++j) {
+            const int e = tid + j * 256;
             const int xx = e % (GTW + 2), hy = (e / (GTW + 2)) % (GTH + 2), dz = e / ((GTW + 2) * (GTH + 2));
             const int gz = d0 - 1 + dz, gyy = h0 - 1 + hy, gx = w0 - 1 + xx;
-            float v = 0.f;
-            if ((unsigned)gz < (unsigned)D && (unsigned)gyy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                v = gy[(size_t)b * DHW + (size_t)gz * HW + (size_t)gyy * W + gx];
-            Gs[dz * GPS + hy * GRS + xx] = v;
+            const bool ok = live && e < NGH && (unsigned)gz < (unsigned)D && (unsigned)gyy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            gr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  grs, ok ? (unsigned)(gz * (int)HW + gyy * W + gx) * 4u : 0x80000000u, 0, 0));
         }
+    };
+    prefetch(blockIdx.x);
+    for (unsigned tile = blockIdx.x; tile < (unsigned)ntiles; tile += gridDim.x) {
         __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Xs[cc * GXSTR + tid + j * 256] = xr[cc * 2 + j];
+#pragma unroll
+        for (int j = 0; j < PG; ++j)
+            if (gdst[j] >= 0) Gs[gdst[j]] = gr[j];
+        __syncthreads();
+        prefetch(tile + gridDim.x);
         // k-steps: two x-adjacent voxels; wave handles rows {wave, wave+4, ...} of the 16 tile rows
         const float* xa = Xs + l31 * GXSTR + half;
         const float* gb = Gs + toff + half;
@@ -222,12 +245,33 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad(const float* __restrict__
     }
 }
 
-__global__ void c1_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, int n, int P) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// gw[i] = sum_p partial[p][i] in a fixed order: 32 outputs per workgroup, 8 lane groups each sum every 8th partial
+// (same scheme as wgrad_reduce in conv3d_wgrad.hip; one thread per output walking 512 partials took ~0.1 ms).
+__global__ __launch_bounds__(256) void c1_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, int n, int P) {
+    __shared__ float sm[8][32];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partial[(size_t)p * n + i];
-    gw[i] = s;
+    if (i < n) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = grp;
+        for (; p + 24 < P; p += 32) {
+            s0 += partial[(size_t)p * n + i];
+            s1 += partial[(size_t)(p + 8) * n + i];
+            s2 += partial[(size_t)(p + 16) * n + i];
+            s3 += partial[(size_t)(p + 24) * n + i];
+        }
+        for (; p < P; p += 8) s0 += partial[(size_t)p * n + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    sm[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += sm[g][o];
+        gw[i] = t;
+    }
 }
 
 inline int c1_workers(long long ntiles) { return (int)(ntiles < 512 ? ntiles : 512); }
@@ -260,7 +304,7 @@ extern "C" long long ecm_conv3d_c1_wgrad_scratch_bytes(int B, int Ci, int D, int
 extern "C" int ecm_conv3d_c1_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B,
                                    int Ci, int D, int H, int W, void* stream) {
     ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && D > 0 && H > 0 && W > 0);
-    if (Ci > 32 || (long long)D * H * W * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;
+    if (Ci > 32 || (long long)D * H * W * 4 * 32 >= 0x7fffffffLL || c1_tiles(B, D, H, W) >= 0x7fffffffLL) return ECM_EUNSUP;
     if (scratch_bytes < ecm_conv3d_c1_wgrad_scratch_bytes(B, Ci, D, H, W)) return ECM_ESCRATCH;
     const int tiles_d = (D + GTD - 1) / GTD, tiles_h = (H + GTH - 1) / GTH, tiles_w = (W + GTW - 1) / GTW;
     const int P = c1_workers(c1_tiles(B, D, H, W));
@@ -273,6 +317,6 @@ extern "C" int ecm_conv3d_c1_wgrad(const float* x, const float* gy, float* gw, v
     hipLaunchKernelGGL(conv3d_c1_wgrad, dim3(P), dim3(256), G_LDS_BYTES, st, x, gy, partial, B, Ci, D, H, W, tiles_d, tiles_h,
                        tiles_w);
     const int n = Ci * 27;
-    hipLaunchKernelGGL(c1_wgrad_reduce, dim3((n + 255) / 256), dim3(256), 0, st, partial, gw, n, P);
+    hipLaunchKernelGGL(c1_wgrad_reduce, dim3((n + 31) / 32), dim3(256), 0, st, partial, gw, n, P);
     return ECM_LAUNCH_RESULT();
 }

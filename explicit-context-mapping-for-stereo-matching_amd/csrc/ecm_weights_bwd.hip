@@ -437,21 +437,47 @@ __global__ __launch_bounds__(128) void ecm_weights_bwd_cells(const float* __rest
     for (int u = 0; u < 8; ++u) pc[u] = a[u];
 }
 
-// Kernel D: gW = [gW0 (32x66) | gW1 (16x32) | gW2 (8x16) | gW3 (8)], fixed-order sums of the partials.
-__global__ void ecm_weights_bwd_reduce(const float* __restrict__ partB, int nB, const float* __restrict__ partC, int nC,
-                                       float* __restrict__ gW) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= 2760) return;
+// Kernel D: gW = [gW0 (32x66) | gW1 (16x32) | gW2 (8x16) | gW3 (8)], fixed-order sums of the partials: a workgroup owns
+// 32 outputs, its 8 lane groups each sum every 8th partial, and the 8 group sums are added in order (one thread per
+// output walking up to ~1000 partials was latency-bound: 0.56 ms).
+__global__ __launch_bounds__(256) void ecm_weights_bwd_reduce(const float* __restrict__ partB, int nB,
+                                                              const float* __restrict__ partC, int nC,
+                                                              float* __restrict__ gW) {
+    __shared__ float sm[8][32];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + o;
     float s = 0.f;
-    if (k < 2112) {
-        const int j = k / 66, c = k - j * 66;
-        if (c < 32) { for (int p = 0; p < nC; ++p) s += partC[(size_t)p * 1024 + j * 32 + c]; }
-        else if (c < 64) { for (int p = 0; p < nB; ++p) s += partB[(size_t)p * PB_N + PB_HR + j * 32 + (c - 32)]; }
-        else { for (int p = 0; p < nB; ++p) s += partB[(size_t)p * PB_N + PB_OFF + j * 2 + (c - 64)]; }
-    } else if (k < 2624) { for (int p = 0; p < nB; ++p) s += partB[(size_t)p * PB_N + PB_W1 + (k - 2112)]; }
-    else if (k < 2752) { for (int p = 0; p < nB; ++p) s += partB[(size_t)p * PB_N + PB_W2 + (k - 2624)]; }
-    else { for (int p = 0; p < nB; ++p) s += partB[(size_t)p * PB_N + PB_W3 + (k - 2752)]; }
-    gW[k] = s;
+    if (k < 2760) {
+        const float* src;
+        size_t stride;
+        int n;
+        if (k < 2112) {
+            const int j = k / 66, c = k - j * 66;
+            if (c < 32) { src = partC + j * 32 + c; stride = 1024; n = nC; }
+            else if (c < 64) { src = partB + PB_HR + j * 32 + (c - 32); stride = PB_N; n = nB; }
+            else { src = partB + PB_OFF + j * 2 + (c - 64); stride = PB_N; n = nB; }
+        } else if (k < 2624) { src = partB + PB_W1 + (k - 2112); stride = PB_N; n = nB; }
+        else if (k < 2752) { src = partB + PB_W2 + (k - 2624); stride = PB_N; n = nB; }
+        else { src = partB + PB_W3 + (k - 2752); stride = PB_N; n = nB; }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = grp;
+        for (; p + 24 < n; p += 32) {
+            s0 += src[(size_t)p * stride];
+            s1 += src[(size_t)(p + 8) * stride];
+            s2 += src[(size_t)(p + 16) * stride];
+            s3 += src[(size_t)(p + 24) * stride];
+        }
+        for (; p < n; p += 8) s0 += src[(size_t)p * stride];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    sm[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && k < 2760) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += sm[g][o];
+        gW[k] = t;
+    }
 }
 
 struct BwdPlan { long long ntiles; int tiles_x, nB, nC; long long offA, offA9, offPB, offPC, total; };
@@ -488,7 +514,7 @@ int launch_bwd(const float* lr, const float* hr, const float* W0, const float* W
     hipLaunchKernelGGL(ecm_weights_bwd_kernel<VAR>, dim3(p.nB), dim3(256), BWD_LDS_BYTES, st, A, hr, W0, W1, W2, W3, saved,
                        gout, ghr, gA9, partB, B, h, w, s, p.tiles_x);
     hipLaunchKernelGGL(ecm_weights_bwd_cells<VAR>, dim3(p.nC), dim3(128), 0, st, gA9, lr, W0, glr, partC, B, h, w, s);
-    hipLaunchKernelGGL(ecm_weights_bwd_reduce, dim3((2760 + 255) / 256), dim3(256), 0, st, partB, p.nB, partC, p.nC, gW);
+    hipLaunchKernelGGL(ecm_weights_bwd_reduce, dim3((2760 + 31) / 32), dim3(256), 0, st, partB, p.nB, partC, p.nC, gW);
     return ECM_LAUNCH_RESULT();
 }
 

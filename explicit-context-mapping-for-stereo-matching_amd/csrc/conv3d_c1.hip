@@ -2,7 +2,8 @@
 // forward and weight gradient.  With ONE output channel the generic implicit GEMM wastes 31/32 of every MFMA, so the
 // contraction is re-associated:
 //   forward:  T[tap][u] = sum_ci w[ci,tap] x[ci,u]   (a 27 x Ci x voxels GEMM on the fp32 matrix cores, M = taps),
-//             y[v] = sum_tap T[tap][v + off(tap)]     (27 shifted adds out of LDS, fixed order => deterministic)
+//             y[v] = sum_tap T[tap][v + off(tap)]     (27 shifted adds out of LDS, fixed order => deterministic),
+//             one input plane at a time, marching along the disparity axis
 //   wgrad:    gw[ci,tap] = sum_u x[ci,u] * gy[u - off(tap)]  (M = ci, N = taps, K = voxels: one MFMA per two voxels
 //             covers all 32 x 27 products; the tap shift is a per-lane LDS offset on the small gy tile)
 // Both are then bound by reading x once (212 MB at 576x960) instead of by ~92 GFLOP of padded MFMA work.
@@ -13,29 +14,35 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------ forward
-constexpr int FTD = 2, FTH = 4, FTW = 30;                  // output tile; input tile (FTD+2) x (FTH+2) rows of 32 columns
-constexpr int FID = FTD + 2, FIH = FTH + 2, FROWS = FID * FIH;          // 24 input rows
-constexpr int FRW = FROWS / 4;                                           // rows per wave
-constexpr int FCIC = 8;                                                  // input channels per staged chunk
-constexpr int F_XS = FCIC * FROWS * 32;                                  // staged x floats
-constexpr int F_TS = 27 * FROWS * 32;                                    // T image floats  [tap][row][32]
-constexpr int F_LDS_BYTES = (F_XS + F_TS) * 4;
+// Depth-marching: a workgroup owns an MTH x MTW output footprint and walks a range of input planes z.  Per plane:
+//   stage x[all 32 ci][(MTH+2) x 32 window] (register-prefetched one plane ahead),
+//   T[tap][pos] = sum_ci w[ci,tap] x[ci,pos]              (27 x 32 x 256 GEMM: 8 MFMA row-blocks, 2 per wave),
+//   S_kd[h,w] = sum_{kh,kw} T[kd,kh,kw][h+kh, w+kw]        (27 LDS reads per output position),
+//   out[z+1] += S_0, out[z] += S_1, out[z-1] += S_2        (rolling registers; out[z-1] is complete and written).
+// Only one plane of T lives in LDS (27.6 KB instead of 83 KB for a 3-D tile), so two workgroups share a CU, and the
+// halo is re-read in-plane only (1.42x instead of 3.2x).
+constexpr int MTH = 6, MTW = 30;                          // output footprint per plane
+constexpr int MIH = MTH + 2, MPOS = MIH * 32;             // 8 window rows of 32 columns = 256 positions (1 per thread)
+constexpr int MXS = MPOS + 32;                            // channel stride of the x image (== 32 mod 64: the two k halves
+                                                          //   of a B-operand read land on different banks)
+constexpr int M_LDS_BYTES = (32 * MXS + 27 * MPOS) * 4;   // 36.9 KB + 27.6 KB
+static_assert(MPOS == 256, "one window position per thread");
 
-__global__ __launch_bounds__(256) void conv3d_c1_fwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                     float* __restrict__ y, int Ci, int D, int H, int W, int tiles_d,
-                                                     int tiles_h, int tiles_w) {
+__global__ __launch_bounds__(256, 2) void conv3d_c1_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, int Ci, int D, int H, int W, int zchunk,
+                                                        int tiles_z, int tiles_h, int tiles_w) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                 // [FCIC][FROWS][32]
-    float* Ts = smem + F_XS;          // [27][FROWS][32]
+    float* Xs = smem;                 // [32 ci][MXS]
+    float* Ts = smem + 32 * MXS;      // [27 taps][MPOS]
     int bid = blockIdx.x;
     const int tw = bid % tiles_w; bid /= tiles_w;
     const int th = bid % tiles_h; bid /= tiles_h;
-    const int td = bid % tiles_d;
-    const int b = bid / tiles_d;
-    const int od0 = td * FTD, oh0 = th * FTH, ow0 = tw * FTW;
+    const int tz = bid % tiles_z;
+    const int b = bid / tiles_z;
+    const int z0 = tz * zchunk, z1 = z0 + zchunk < D ? z0 + zchunk : D;      // output planes [z0, z1)
+    const int oh0 = th * MTH, ow0 = tw * MTW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
-    const float* xb = x + (size_t)b * Ci * DHW;
 
     // A operand (weights) for every k-step, kept in registers: lane holds w[ci = 2*kk + half][tap = l31]
     float wa[16];
@@ -44,83 +51,73 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd(const float* __restrict__ x
         const int ci = 2 * kk + half;
         wa[kk] = (l31 < 27 && ci < Ci) ? w[(size_t)ci * 27 + l31] : 0.f;
     }
-    // staging: thread owns 3 fixed (row, column) positions of the 24 x 32 input window (768 = 3 x 256)
-    unsigned posoff[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int p = tid + j * 256;
-        const int xx = p & 31, row = p >> 5;
-        const int dz = row / FIH, hy = row - dz * FIH;
-        const int gz = od0 - 1 + dz, gy = oh0 - 1 + hy, gx = ow0 - 1 + xx;
-        const bool ok = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        posoff[j] = ok ? (unsigned)(gz * (int)HW + gy * W + gx) * 4u : 0x80000000u;
-    }
+    // staging: thread owns window position tid = (row, column) for all channels; in-plane offset is plane-invariant
+    const int prow = tid >> 5, pcol = tid & 31;
+    const int gyy = oh0 - 1 + prow, gx = ow0 - 1 + pcol;
+    const bool inplane = (unsigned)gyy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const unsigned inoff = (unsigned)(gyy * W + gx) * 4u;
     const unsigned plane_bytes = (unsigned)DHW * 4u;
-    float xr[FCIC * 3];
-    auto prefetch = [&](int c0) {
+    const int nci = Ci < 32 ? Ci : 32;
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * Ci * DHW), 0,
+                                                       (unsigned)nci * plane_bytes, 0x00020000);
+    float xr[32];
+    auto prefetch = [&](int z) {      // input plane z (may be outside [0, D): zeros)
+        const bool ok = inplane && (unsigned)z < (unsigned)D;
+        const unsigned off = ok ? (unsigned)z * (unsigned)HW * 4u + inoff : 0x80000000u;
 #pragma unroll
-        for (int cc = 0; cc < FCIC; ++cc) {
-            const bool cok = c0 + cc < Ci;
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(cok ? c0 + cc : 0) * DHW), 0,
-                                                                cok ? plane_bytes : 0u, 0x00020000);
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                xr[cc * 3 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, posoff[j], 0, 0));
-        }
+        for (int cc = 0; cc < 32; ++cc)
+            xr[cc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off + (unsigned)cc * plane_bytes, 0, 0));
     };
-    f32x16 acc[FRW];
-#pragma unroll
-    for (int r = 0; r < FRW; ++r)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+    // output position of this thread (threads >= MTH*MTW only help with staging and the GEMM)
+    const bool owner = tid < MTH * MTW;
+    const int ohy = tid / MTW, oxo = tid - ohy * MTW;
+    const bool ovalid = owner && oh0 + ohy < H && ow0 + oxo < W;
+    float* yp = y + (size_t)b * DHW + (size_t)(oh0 + ohy) * W + (ow0 + oxo);
+    float r_prev = 0.f, r_cur = 0.f;                       // partial sums of out[z-1], out[z]
 
-    prefetch(0);
-    for (int c0 = 0; c0 < Ci; c0 += FCIC) {
+    prefetch(z0 - 1);
+    for (int z = z0 - 1; z <= z1; ++z) {                   // input planes z0-1 .. z1 (zero planes outside the volume)
+        __syncthreads();                                   // previous plane's T reads and x reads are done
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc) Xs[cc * MXS + tid] = xr[cc];
         __syncthreads();
+        if (z < z1) prefetch(z + 1);
+        f32x16 acc[2];
 #pragma unroll
-        for (int cc = 0; cc < FCIC; ++cc)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) Xs[cc * FROWS * 32 + tid + j * 256] = xr[cc * 3 + j];
+            for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float bv = Xs[(kk * 2 + half) * MXS + (wave * 2 + r) * 32 + l31];
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[kk], bv, acc[r], 0, 0, 0);
+            }
+        // T[tap][row][col] -> LDS   (D fragment: column = l31, register i = tap (i&3) + 8*(i>>2) + 4*half)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int tap = (i & 3) + 8 * (i >> 2) + 4 * half;
+                if (tap < 27) Ts[tap * MPOS + (wave * 2 + r) * 32 + l31] = acc[r][i];
+            }
         __syncthreads();
-        if (c0 + FCIC < Ci) prefetch(c0 + FCIC);
+        if (owner) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;            // S_kd of this plane at (ohy, oxo), taps in fixed order
 #pragma unroll
-        for (int kk = 0; kk < FCIC / 2; ++kk) {
-            // wa index of this chunk's k-step: channels c0 + 2*kk + half  (c0 is a multiple of 8 => static within 32)
-            float a;
-            switch (c0 >> 3) {
-                case 0: a = wa[kk]; break;
-                case 1: a = wa[4 + kk]; break;
-                case 2: a = wa[8 + kk]; break;
-                default: a = wa[12 + kk]; break;
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int kh = t9 / 3, kw = t9 % 3;
+                const int o = (ohy + kh) * 32 + oxo + kw;
+                s0 += Ts[(0 * 9 + t9) * MPOS + o];
+                s1 += Ts[(1 * 9 + t9) * MPOS + o];
+                s2 += Ts[(2 * 9 + t9) * MPOS + o];
             }
-#pragma unroll
-            for (int r = 0; r < FRW; ++r) {
-                const float bv = Xs[((kk * 2 + half) * FROWS + wave * FRW + r) * 32 + l31];
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[r], 0, 0, 0);
-            }
-        }
-    }
-    // T[tap][row][x] -> LDS   (D fragment: column = x, register i = tap (i&3) + 8*(i>>2) + 4*half)
-#pragma unroll
-    for (int r = 0; r < FRW; ++r)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int tap = (i & 3) + 8 * (i >> 2) + 4 * half;
-            if (tap < 27) Ts[(tap * FROWS + wave * FRW + r) * 32 + l31] = acc[r][i];
-        }
-    __syncthreads();
-    // y[dz,hy,x] = sum_tap T[tap][(dz+kd, hy+kh)][x+kw]   -- 240 outputs, one per thread, taps in fixed order
-    if (tid < FTD * FTH * FTW) {
-        const int xo = tid % FTW, hy = (tid / FTW) % FTH, dz = tid / (FTW * FTH);
-        const int od = od0 + dz, oh = oh0 + hy, ow = ow0 + xo;
-        if (od < D && oh < H && ow < W) {
-            float s = 0.f;
-#pragma unroll
-            for (int tap = 0; tap < 27; ++tap) {
-                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                s += Ts[(tap * FROWS + (dz + kd) * FIH + hy + kh) * 32 + xo + kw];
-            }
-            y[(size_t)b * DHW + (size_t)od * HW + (size_t)oh * W + ow] = s;
+            // plane z feeds out[z+1] (kd=0), out[z] (kd=1), out[z-1] (kd=2); out[z-1] is now complete
+            const float done = r_prev + s2;
+            if (ovalid && z - 1 >= z0 && z - 1 < z1) yp[(size_t)(z - 1) * HW] = done;
+            r_prev = r_cur + s1;
+            r_cur = s0;
         }
     }
 }
@@ -283,16 +280,23 @@ inline long long c1_tiles(int B, int D, int H, int W) {
 
 extern "C" int ecm_conv3d_c1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, void* stream) {
     ECM_CHECK_ARG(x && w && y && B > 0 && Ci > 0 && D > 0 && H > 0 && W > 0);
-    if (Ci > 32 || Ci % FCIC != 0 || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
-    const int tiles_d = (D + FTD - 1) / FTD, tiles_h = (H + FTH - 1) / FTH, tiles_w = (W + FTW - 1) / FTW;
-    const long long nblk = (long long)B * tiles_d * tiles_h * tiles_w;
+    if (Ci > 32 || (long long)D * H * W * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;
+    const int tiles_h = (H + MTH - 1) / MTH, tiles_w = (W + MTW - 1) / MTW;
+    // split the disparity axis only as far as needed to give the chip ~3 rounds of workgroups (each chunk re-reads 2 planes)
+    const long long cols = (long long)B * tiles_h * tiles_w;
+    int tiles_z = (int)((3 * 512 + cols - 1) / cols);
+    if (tiles_z < 1) tiles_z = 1;
+    if (tiles_z > (D + 7) / 8) tiles_z = (D + 7) / 8;
+    const int zchunk = (D + tiles_z - 1) / tiles_z;
+    tiles_z = (D + zchunk - 1) / zchunk;
+    const long long nblk = cols * tiles_z;
     if (nblk > 0x7fffffffLL) return ECM_EUNSUP;
     {
-        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(conv3d_c1_fwd), F_LDS_BYTES);
+        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(conv3d_c1_fwd), M_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(conv3d_c1_fwd, dim3((unsigned)nblk), dim3(256), F_LDS_BYTES, ecm_stream(stream), x, w, y, Ci, D, H, W,
-                       tiles_d, tiles_h, tiles_w);
+    hipLaunchKernelGGL(conv3d_c1_fwd, dim3((unsigned)nblk), dim3(256), M_LDS_BYTES, ecm_stream(stream), x, w, y, Ci, D, H, W,
+                       zchunk, tiles_z, tiles_h, tiles_w);
     return ECM_LAUNCH_RESULT();
 }
 

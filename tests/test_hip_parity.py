@@ -221,7 +221,8 @@ def test_groupnorm(ecm, B, C, dims, relu, skip):
 @pytest.mark.parametrize("B,Ci,Co,dims,stride", [
     (1, 32, 32, (4, 8, 32), 1), (1, 64, 32, (8, 8, 12), 1), (2, 32, 32, (5, 9, 37), 1), (1, 32, 1, (8, 8, 12), 1),
     (1, 32, 64, (8, 16, 24), 2), (1, 64, 64, (4, 8, 12), 1), (1, 64, 64, (8, 8, 12), 2), (1, 32, 64, (6, 10, 70), 2),
-    (1, 32, 32, (12, 20, 60), 1)])
+    (1, 32, 32, (12, 20, 60), 1), (2, 32, 1, (20, 14, 70), 1), (1, 16, 1, (5, 7, 33), 1), (1, 32, 1, (33, 6, 30), 1),
+    (1, 8, 1, (2, 3, 4), 1)])
 def test_conv3d_fwd(ecm, B, Ci, Co, dims, stride):
     x = seeded("cv3.x", B, Ci, *dims)
     w = seeded("cv3.w", Co, Ci, 3, 3, 3) * (2.0 / (27 * Ci)) ** 0.5
@@ -257,7 +258,9 @@ def test_deconv3d_fwd(ecm, B, Ci, Co, dims):
 
 @pytest.mark.parametrize("B,Ci,Co,dims,stride", [
     (1, 32, 32, (4, 8, 32), 1), (2, 64, 32, (4, 6, 20), 1), (1, 32, 1, (8, 8, 12), 1), (1, 32, 64, (8, 16, 24), 2),
-    (1, 64, 64, (4, 8, 12), 1), (2, 64, 64, (8, 8, 12), 2), (1, 32, 32, (5, 7, 19), 1)])
+    (1, 64, 64, (4, 8, 12), 1), (2, 64, 64, (8, 8, 12), 2), (1, 32, 32, (5, 7, 19), 1),
+    # the classifier's 32 -> 1 layer: several footprints, ragged edges, several disparity chunks
+    (2, 32, 1, (20, 14, 70), 1), (1, 16, 1, (5, 7, 33), 1), (1, 32, 1, (33, 6, 30), 1)])
 def test_conv3d_bwd(ecm, B, Ci, Co, dims, stride):
     x = seeded("cb3.x", B, Ci, *dims)
     w = seeded("cb3.w", Co, Ci, 3, 3, 3) * (2.0 / (27 * Ci)) ** 0.5
@@ -268,7 +271,8 @@ def test_conv3d_bwd(ecm, B, Ci, Co, dims, stride):
     G = seeded("cb3.G", *ref.shape)
     y.backward(dev(G)); ref.backward(G)
     close(xg.grad, xc.grad, 1e-4, 1e-5)
-    close(wg.grad, wc.grad, 1e-4, 1e-4)
+    # a weight gradient is a sum over every voxel: the absolute tolerance scales with the magnitude of the sums
+    close(wg.grad, wc.grad, 1e-4, 1e-5 * max(10.0, float(wc.grad.abs().max())))
 
 
 @pytest.mark.parametrize("B,Ci,Co,dims", [(1, 64, 64, (2, 4, 6)), (2, 64, 32, (3, 5, 19))])

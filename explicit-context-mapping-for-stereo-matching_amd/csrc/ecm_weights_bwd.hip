@@ -92,8 +92,11 @@ __device__ __forceinline__ float mlp_forward(const float* __restrict__ a, const 
     return o;
 }
 
+// Two workgroups per CU: the kernel wants ~330 registers, so this bound spills ~65 of them to scratch, but a second
+// resident workgroup hides the scalar-cache weight loads and the two barriers per neighbour that a lone wave per SIMD
+// cannot (measured at 576x960: 1.54 ms at one workgroup per CU without spills, 1.10 ms at two with).
 template <int VAR>
-__global__ __launch_bounds__(256, 1) void ecm_weights_bwd_kernel(
+__global__ __launch_bounds__(256, 2) void ecm_weights_bwd_kernel(
     const float* __restrict__ A, const float* __restrict__ hr, const float* __restrict__ W0, const float* __restrict__ W1,
     const float* __restrict__ W2, const float* __restrict__ W3, const float* __restrict__ wsaved,
     const float* __restrict__ gw, float* __restrict__ ghr, float* __restrict__ gA9, float* __restrict__ partB, int B, int h,

@@ -101,6 +101,12 @@ def main():
     W0, W1, W2, W3 = (torch.randn(*s, device=dev) * 0.2 for s in ((32, 66, 1, 1), (16, 32, 1, 1), (8, 16, 1, 1), (1, 8, 1, 1)))
     report("ecm_weights9 fwd 576x960", timeit(lambda: ops.ecm_weights9(lr, hr, W0, W1, W2, W3)),
            (hr.numel() + lr.numel() + 9 * 576 * 960) * 4 / 1e6, gflop=7.7)
+    lrg, hrg = lr.clone().requires_grad_(), hr.clone().requires_grad_()
+    Wg = [t.clone().requires_grad_() for t in (W0, W1, W2, W3)]
+    w9o = ops.ecm_weights9(lrg, hrg, *Wg)
+    g9 = torch.randn_like(w9o)
+    report("ecm_weights9 bwd 576x960", timeit(lambda: torch.autograd.grad(w9o, [lrg, hrg] + Wg, g9, retain_graph=True)),
+           (2 * hr.numel() + 2 * lr.numel() + 18 * 576 * 960) * 4 / 1e6)
     c = torch.randn(3, B, D, h, w, device=dev)
     report("softargmin 3 heads", timeit(lambda: ops.softargmin_heads(c)), c.numel() * 4 / 1e6)
     d = ops.softargmin_heads(c)

@@ -210,13 +210,15 @@ def main():
                 traffic_conv = pm["conv3d_k3_mfma<1,1,4,8,4> 32->32"]["hbm_bytes_per_launch_B1"] * B
         except (OSError, KeyError, ValueError):
             pass
+        shape_name = {(576, 960): "SceneFlow 960x540 (padded to 576)",
+                      (384, 1248): "KITTI-2015 1242x375 (padded to 1248x384)"}.get((H, W), f"synthetic {W}x{H}")
         out = {
             "metric": "stereo-pairs/sec (cmfsm train step fwd+bwd+Adam)" if args.mode == "train"
                       else "stereo-pairs/sec (cmfsm eval forward)",
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"SceneFlow {W}x540 (padded to {H}) D={D} batch={B}/GPU "
+            "config": {"workload": f"{shape_name} D={D} batch={B}/GPU "
                                    f"{'fwd+bwd+Adam (train.py path)' if args.mode == 'train' else 'eval forward (test.py path)'}",
                        "arch": "cmfsm", "global_batch": B * world, "parallelism": f"dp{world}",
                        "cost_volume": "explicit 4-D tensor" if args.explicit_cost_volume else "collapsed into 2-D convolutions"},

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "ecm_stereo_loss_bwd": (_I, [_P] * 9 + [_LL, _F, _F, _F, _F, _P]),
     "ecm_costvol_conv_assemble_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ecm_costvol_conv_assemble_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ecm_frame_prep": (_I, [_P] * 5 + [_I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "ecm_gn3d_scratch_bytes": (_LL, [_I, _I, _LL]),
     "ecm_gn3d_stats": (_I, [_P, _P, _P, _LL, _I, _I, _LL, _F, _P]),
     "ecm_gn3d_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _LL, _I, _P]),

@@ -594,6 +594,32 @@ class GroupNormAct(torch.autograd.Function):
         return gx, ggamma, gbeta, gskip, None
 
 
+FLYING3D_MEAN, FLYING3D_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # cmf/loader/Flying3d.py:26-27
+
+
+def frame_prep(frames, crop_y0, crop_x0, th, tw, split=None, tail=0, mean=FLYING3D_MEAN, std=FLYING3D_STD, want_image=False):
+    """Batched GPU form of Flying3d.__getitem__ + transform (cmf/loader/Flying3d.py:49-99): frames [B,H,W,7] float32
+    (resident) -> left, right [B,3,th,tw] normalised, disparity [B,th,tw] (and the raw left image in CHW).
+    Train: th, tw = 256, 512 and crop_y0/crop_x0 = the window origins the loader draws at random.  Eval on 540x960 frames:
+    th, tw = 576, 960, crops 0, split=540, tail=36 (the last 36 rows are appended again)."""
+    _chk(frames)
+    frames = _c(frames)
+    B, H, W, ch = frames.shape
+    if ch != 7:
+        raise RuntimeError(f"frame_prep expects [B,H,W,7] frames (left RGB, right RGB, disparity), got {tuple(frames.shape)}")
+    split = th if split is None else int(split)
+    ys = (C.c_int * B)(*[int(v) for v in crop_y0])
+    xs = (C.c_int * B)(*[int(v) for v in crop_x0])
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    left = torch.empty(B, 3, th, tw, device=frames.device, dtype=frames.dtype)
+    right = torch.empty_like(left)
+    disp = torch.empty(B, th, tw, device=frames.device, dtype=frames.dtype)
+    image = torch.empty_like(left) if want_image else None
+    _lib.call("ecm_frame_prep", _p(frames), _p(left), _p(right), _p(disp), _p(image), B, H, W, ys, xs, int(th), int(tw), split,
+              int(tail), m3, s3, _stream())
+    return (left, right, disp, image) if want_image else (left, right, disp)
+
+
 class StereoLoss3(torch.autograd.Function):
     """Loss of the training scripts and the KITTI validation metrics in one pass (train.py:162,172-174;
     train_kitti.py:205-216).  Returns (loss, metrics[8]); metrics = [loss, #mask, epe, err3 %, m1, m2, m3, 0] (no grad)."""

@@ -181,6 +181,15 @@ int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, con
 int ecm_costvol_conv_assemble_fwd(const float* P, const float* Qp, float* y, int B, int Co, int D, int h, int w, void* stream);
 int ecm_costvol_conv_assemble_bwd(const float* gy, float* gP, float* gQp, int B, int Co, int D, int h, int w, void* stream);
 
+/* Input side of the harness (cmf/loader/Flying3d.py:49-99): a batch of resident float32 frames [B,H,W,7] = (left RGB,
+ * right RGB, disparity) -> left, right [B,3,th,tw] = ((v/255) - mean[c]) / std[c], disp [B,th,tw], and optionally
+ * image [B,3,th,tw] = the raw left image in CHW (NULL to skip).  Output row r < split reads frame row crop_y0[b]+r, row
+ * r >= split reads frame row H-tail+(r-split) (eval: split 540, tail 36 -> 576 rows; train: split == th); columns
+ * crop_x0[b] .. +tw.  crop_y0 / crop_x0 / mean3 / std3 are HOST arrays (B ints / 3 floats).  Bit-identical to the loader. */
+int ecm_frame_prep(const float* frames, float* left, float* right, float* disp, float* image, int B, int H, int W,
+                   const int* crop_y0, const int* crop_x0, int th, int tw, int split, int tail,
+                   const float* mean3, const float* std3, void* stream);
+
 /* Harness loss + metrics (train.py:162,172-174; train_kitti.py:205-216) over n = B*H*W pixels; mask = 0 < gt < maxdisp.
  * out8 (device): [loss, #mask, epe(p3), err3(p3) in %, mean smooth-L1 of p1, p2, p3, 0];
  * loss = w1*m1 + w2*m2 + w3*m3 (reference weights 0.5 / 0.7 / 1.0).  Empty mask -> NaN (as the reference's empty mean).

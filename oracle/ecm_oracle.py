@@ -296,6 +296,38 @@ def train_loss(preds, gt, maxdisp=192):
             + F.smooth_l1_loss(o3[mask], gt[mask], reduction="mean"))
 
 
+FLYING3D_MEAN, FLYING3D_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # Flying3d.py:26-27
+
+
+def flying3d_sample(frame, split="train", crop=(0, 0)):
+    """cmf/loader/Flying3d.py:49-99 for one float32 frame [H,W,7] (left RGB, right RGB, disparity; flying3ddata.py:34-39)
+    -> (left [3,h,w], right [3,h,w], disparity [h,w], image [3,h,w]).  `crop` = the (x1, y1) the loader draws with
+    random.randint in train mode (row, column of the 256x512 window).  torchvision's ToTensor on a float ndarray is a
+    HWC->CHW transpose (no scaling) and Normalize is `(t - mean[:,None,None]) / std[:,None,None]` in the tensor's dtype;
+    torchvision is absent from this image, so these two documented semantics are restated here (parity unpinned for
+    them -- the crop/pad/scale arithmetic is the loader's own numpy code, line by line)."""
+    import numpy as np
+    data = np.asarray(frame)
+    if split == "train":
+        x1, y1 = crop
+        data = data[x1:x1 + 256, y1:y1 + 512, :]                  # :51-56
+    else:
+        padding = data[-36:, ...]                                  # :66
+        data = np.concatenate([data[0:540, 0:960, :], padding], 0)  # :67-71
+    left = data[..., 0:3] / 255                                    # :73
+    image = torch.from_numpy(np.ascontiguousarray(data[..., 0:3].transpose(2, 0, 1)))      # :75-76 ToTensor on floats
+    right = data[..., 3:6] / 255                                   # :78
+    disparity = data[..., 6]                                       # :79
+    mean = torch.tensor(FLYING3D_MEAN, dtype=torch.float32)[:, None, None]
+    std = torch.tensor(FLYING3D_STD, dtype=torch.float32)[:, None, None]
+
+    def trans(a):                                                  # :90-96 ToTensor + Normalize, then .float()
+        t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+        return ((t - mean.to(t.dtype)) / std.to(t.dtype)).float()
+
+    return trans(left), trans(right), torch.from_numpy(np.ascontiguousarray(disparity)).float(), image
+
+
 def kitti_metrics(pred3, gt, maxdisp=192):
     """train_kitti.py:213-216: end-point error and the 3-px / 5 % error rate (in %) of the last head over the mask."""
     mask = (gt < maxdisp) & (gt > 0)

@@ -443,6 +443,38 @@ def test_stereo_loss3(ecm, B, H, W):
         ecm.ops.stereo_loss3([gpu[0], gpu[1], gpu[2][:, :, :-1]], dev(gt))
 
 
+def _frames(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    rgb = torch.randint(0, 256, (B, H, W, 6), generator=g).float()          # uint8 images promoted to float32
+    disp = torch.rand(B, H, W, 1, generator=g) * 300.0
+    return torch.cat([rgb, disp], -1).contiguous()
+
+
+def test_frame_prep_train_crop_bit_exact(ecm):
+    """GPU frame preparation == Flying3d.__getitem__ (train split) for given crop origins, bit for bit."""
+    fr = _frames(3, 300, 620, 5)
+    y0, x0 = [0, 44, 17], [108, 0, 61]
+    l, r, d, im = ecm.ops.frame_prep(dev(fr), y0, x0, 256, 512, want_image=True)
+    for b in range(3):
+        L, R, Dp, I = O.flying3d_sample(fr[b].numpy(), "train", (y0[b], x0[b]))
+        assert torch.equal(l[b].cpu(), L) and torch.equal(r[b].cpu(), R)
+        assert torch.equal(d[b].cpu(), Dp) and torch.equal(im[b].cpu(), I)
+
+
+def test_frame_prep_eval_pad_bit_exact(ecm):
+    """Eval split: rows [0,540) then the frame's last 36 rows again (576 rows), 960 columns."""
+    fr = _frames(2, 540, 960, 6)
+    l, r, d = ecm.ops.frame_prep(dev(fr), [0, 0], [0, 0], 576, 960, split=540, tail=36)
+    for b in range(2):
+        L, R, Dp, _ = O.flying3d_sample(fr[b].numpy(), "test")
+        assert L.shape == (3, 576, 960)
+        assert torch.equal(l[b].cpu(), L) and torch.equal(r[b].cpu(), R) and torch.equal(d[b].cpu(), Dp)
+    with pytest.raises(RuntimeError):
+        ecm.ops.frame_prep(dev(fr), [300, 0], [0, 0], 256, 512)             # window outside the frame
+    with pytest.raises(RuntimeError):
+        ecm.ops.frame_prep(dev(fr[..., :6].contiguous()), [0, 0], [0, 0], 256, 512)
+
+
 def test_cpu_tensor_is_refused(ecm):
     with pytest.raises(RuntimeError):
         ecm.ops.cost_volume(torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 4), 2)

@@ -180,3 +180,22 @@ def test_arch_hot_path_oracle_vs_reference(arch):
             ref = g[nm]
             tol = 2e-2 * float(ref.abs().max()) + 1e-6
             assert (t.grad - ref).abs().max() <= tol, (arch, nm, (t.grad - ref).abs().max(), tol)
+
+
+def test_flying3d_sample_restatement():
+    """The loader restatement on a hand-checkable frame (torchvision is absent here: ToTensor / Normalize semantics
+    restated, see the docstring)."""
+    import numpy as np
+    H, W = 540, 960
+    fr = np.zeros((H, W, 7), dtype=np.float32)
+    fr[..., 0:3] = 255.0                       # white left image
+    fr[..., 3:6] = 0.0                         # black right image
+    fr[..., 6] = np.arange(W, dtype=np.float32)[None, :]
+    fr[-1, :, 6] = 7.0
+    L, R, D, I = O.flying3d_sample(fr, "test")
+    assert L.shape == (3, 576, 960) and D.shape == (576, 960) and I.shape == (3, 576, 960)
+    for c, (m, s_) in enumerate(zip(O.FLYING3D_MEAN, O.FLYING3D_STD)):
+        assert abs(float(L[c, 0, 0]) - (1.0 - m) / s_) < 1e-6 and abs(float(R[c, 5, 5]) - (0.0 - m) / s_) < 1e-6
+    assert float(D[10, 123]) == 123.0 and float(D[575, 3]) == 7.0 and float(D[539, 3]) == 7.0      # padded rows = last 36
+    L2, _, D2, _ = O.flying3d_sample(fr, "train", (100, 200))
+    assert L2.shape == (3, 256, 512) and float(D2[0, 0]) == 200.0

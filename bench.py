@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--maxdisp", type=int, default=192)
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="--mode infer only: replay the forward as one captured HIP graph")
     ap.add_argument("--explicit-cost-volume", action="store_true",
                    help="run the reference's explicit op sequence (4-D concat volume + 64->32 Conv3d) instead of the collapsed 2-D form")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -115,10 +116,15 @@ def main():
             return loss
     else:
         model.eval()
+        if args.graph:
+            graphed = ecm_dist.GraphedForward(model, left, right)
 
-        def step():
-            with torch.no_grad():
-                return model(left, right)[2]
+            def step():
+                return graphed(left, right)[2]
+        else:
+            def step():
+                with torch.no_grad():
+                    return model(left, right)[2]
 
     def barrier():
         torch.cuda.synchronize()
@@ -152,7 +158,7 @@ def main():
     # second reading (1 GPU only): the same step with the reference's explicit op sequence -- 4-D concat volume built by
     # the cost-volume kernel + 64->32 Conv3d on it -- so both forms are on record in the same JSON line
     explicit = None
-    if world == 1 and not args.explicit_cost_volume:
+    if world == 1 and not args.explicit_cost_volume and not args.graph:
         mdl = import_module("explicit-context-mapping-for-stereo-matching_amd.models")
         mdl.EXPLICIT_COST_VOLUME = True
         try:
@@ -221,7 +227,8 @@ def main():
             "config": {"workload": f"{shape_name} D={D} batch={B}/GPU "
                                    f"{'fwd+bwd+Adam (train.py path)' if args.mode == 'train' else 'eval forward (test.py path)'}",
                        "arch": "cmfsm", "global_batch": B * world, "parallelism": f"dp{world}",
-                       "cost_volume": "explicit 4-D tensor" if args.explicit_cost_volume else "collapsed into 2-D convolutions"},
+                       "cost_volume": "explicit 4-D tensor" if args.explicit_cost_volume else "collapsed into 2-D convolutions",
+                       "launch": "hip graph replay" if (args.mode == "infer" and args.graph) else "eager"},
             "ms_per_cost_volume": cv_ms / B,
             "roofline": {"kernel": "conv3d_k3_mfma<1,1,4,8,4> (all stride-1, Co<=32 launches: fwd + dgrad)", "bound": "mfma",
                          "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -89,10 +89,10 @@ def _is_convbn(m):
     return isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[1], HipGroupNorm)
 
 
-def _seq_fused(seq, x):
-    """Run an encoder nn.Sequential, folding every `GroupNorm -> ReLU` pair into one fused kernel launch."""
+def _seq_fused(seq, x, start=0):
+    """Run an encoder nn.Sequential (from module `start`), folding every `GroupNorm -> ReLU` pair into one fused launch."""
     mods = list(seq)
-    i = 0
+    i = start
     while i < len(mods):
         m = mods[i]
         relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
@@ -202,6 +202,19 @@ _ENCODERS = {
 }
 
 
+def _pyramid_pools(x, pools):
+    """The SPP branches' AvgPool2d(k, stride k) of the SAME map (cmfsm.py:152-170) computed hierarchically: the smallest
+    window reads the map once, every larger window that is a multiple of a smaller one pools that result (same windows:
+    floor(floor(n/a)/r) == floor(n/(a*r)); only the summation order inside a window changes).  The reference reads the
+    128-channel map once per branch.  `pools`: the branches' nn.AvgPool2d modules; returns their outputs in that order."""
+    ks = [int(p.kernel_size[0] if isinstance(p.kernel_size, tuple) else p.kernel_size) for p in pools]
+    done = {}
+    for k in sorted(set(ks)):
+        base = max((j for j in done if k % j == 0), default=None)
+        done[k] = F.avg_pool2d(x, k, k) if base is None else F.avg_pool2d(done[base], k // base, k // base)
+    return [done[k] for k in ks]
+
+
 class feature_extraction(nn.Module):
     """Returns (low-res 32-ch feature, layer1 output, full-res 32-ch firstconv output)  (cmfsm.py:126-236 and the
     per-architecture copies: cmfsm_sub_8.py:126-236, cmfsm_sub_16.py:127-239, cm_sub_4.py:126-236)."""
@@ -260,7 +273,8 @@ class feature_extraction(nn.Module):
         else:
             output_skip = self.layer4(self.layer3(output_raw))
         size = output_skip.shape[-2:]
-        pyramid = [bilinear_upsample(_seq_fused(getattr(self, f"branch{i}"), output_skip), size) for i in (4, 3, 2, 1)]
+        pooled = _pyramid_pools(output_skip, [getattr(self, f"branch{i}")[0] for i in (1, 2, 3, 4)])
+        pyramid = [bilinear_upsample(_seq_fused(getattr(self, f"branch{i}"), pooled[i - 1], start=1), size) for i in (4, 3, 2, 1)]
         last = self.lastconv_16 if self._raw_is_layer3 else self.lastconv
         feature = _seq_fused(last, torch.cat([output_raw, output_skip] + pyramid, 1))
         return feature, output_rt, output_all

@@ -27,6 +27,16 @@ static inline hipError_t ecm_allow_lds(const void* kern, int bytes) {
     return e;
 }
 
+// XCD-aware tile order.  Workgroup ids are dealt round-robin over the 8 XCDs (id % 8), and each XCD has its own L2, so
+// handing tile `id` to workgroup `id` puts spatial neighbours (which share halo voxels) on eight different L2s.  This
+// maps workgroup id -> tile so that every XCD works through ONE contiguous run of the n tiles: XCD x gets
+// q + (x < r) tiles (q = n / 8, r = n % 8) starting at x*q + min(x, r), and its workgroups x, x+8, x+16, ... take them
+// in order.  A bijection on [0, n).
+__device__ __forceinline__ int ecm_xcd_tile(int id, int n) {
+    const int x = id & 7, q = n >> 3, r = n & 7;
+    return x * q + (x < r ? x : r) + (id >> 3);
+}
+
 // 64-lane wave reductions (CDNA wave = 64).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -55,12 +55,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
     float* Xs = smem;                       // [CIC][ID][IH][RS]
     float* Ws = smem + Cfg::XS_FLOATS;      // 2 x [27][CIC][COP]
 
-    // tile decode (x fastest so neighbouring workgroups share halo rows in L2)
-    int bid = blockIdx.x;
+    // tile decode: one contiguous run of tiles per XCD (ecm_xcd_tile), depth fastest inside it -- depth neighbours share
+    // 2 of their ID input planes (the largest halo overlap), so they should meet in the same L2 at about the same time.
+    // Measured (32->32, B=4, rocprofv3 FETCH_SIZE): L2-miss traffic 1370 -> 767 MB per launch, time 2.95 -> 2.91 ms.
+    int bid = ecm_xcd_tile(blockIdx.x, gridDim.x);
+    const int td = bid % tiles_d; bid /= tiles_d;
     const int tw = bid % tiles_w; bid /= tiles_w;
-    const int th = bid % tiles_h; bid /= tiles_h;
-    const int td = bid % tiles_d;
-    const int b = bid / tiles_d;
+    const int th = bid % tiles_h;
+    const int b = bid / tiles_h;
     const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
     const int id0 = od0 * STRIDE - 1, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
 

@@ -148,11 +148,11 @@ __global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const 
     // Per-tile addressing of the next tile (tile >= ntiles: every offset out of range, the loads return 0 untouched).
     auto prefetch_setup = [&](unsigned tile) {
         const bool live = tile < (unsigned)ntiles;
-        unsigned r = live ? tile : 0u;
+        unsigned r = live ? tile : 0u;                         // depth fastest: depth neighbours share most of their halo
+        const int td = (int)(r % (unsigned)tiles_d); r /= (unsigned)tiles_d;
         const int tw = (int)(r % (unsigned)tiles_w); r /= (unsigned)tiles_w;
-        const int th = (int)(r % (unsigned)tiles_h); r /= (unsigned)tiles_h;
-        const int td = (int)(r % (unsigned)tiles_d);
-        const int b = (int)(r / (unsigned)tiles_d);
+        const int th = (int)(r % (unsigned)tiles_h);
+        const int b = (int)(r / (unsigned)tiles_h);
         const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TWV;
         const int id0 = od0 * STRIDE - Cfg::PADD, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
         const int xbase = id0 * (int)HWi + ih0 * W + iw0;
@@ -184,11 +184,21 @@ __global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const 
 #ifdef WG_PROFILE
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = clock64();
 #endif
-    prefetch_setup((unsigned)blockIdx.x);
+    // XCD-aware persistent schedule: the workers of one XCD (blockIdx.x % 8) walk one contiguous run of the tiles together
+    // (see ecm_xcd_tile), so that halo voxels shared by neighbouring tiles are found in that XCD's L2.
+    unsigned tile0 = blockIdx.x, tile_end = (unsigned)ntiles, tile_step = gridDim.x;
+    if ((gridDim.x & 7u) == 0u) {
+        const unsigned xcd = blockIdx.x & 7u, q = (unsigned)ntiles >> 3, rr = (unsigned)ntiles & 7u;
+        const unsigned start = xcd * q + (xcd < rr ? xcd : rr);
+        tile0 = start + (blockIdx.x >> 3);
+        tile_end = start + q + (xcd < rr ? 1u : 0u);
+        tile_step = gridDim.x >> 3;
+    }
+    prefetch_setup(tile0 < tile_end ? tile0 : (unsigned)ntiles);
 #pragma unroll
     for (int i = 0; i < NLOADS; ++i) prefetch_issue(i);
     WG_T(0);
-    for (unsigned tile = blockIdx.x; tile < (unsigned)ntiles; tile += gridDim.x) {
+    for (unsigned tile = tile0; tile < tile_end; tile += tile_step) {
         __syncthreads();
         WG_T(1);
         // Unconditional stores (positions past the halo tile land in the per-channel pad slot): a guarded store costs
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const 
         WG_T(2);
         __syncthreads();
         WG_T(3);
-        prefetch_setup(tile + gridDim.x);
+        prefetch_setup(tile + tile_step < tile_end ? tile + tile_step : (unsigned)ntiles);
         WG_T(4);
         const float* ga = Gs + l31 * GSTR + half;
         const float* xb = Xs + l31 * XSTR + half * STRIDE;

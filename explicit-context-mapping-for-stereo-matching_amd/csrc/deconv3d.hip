@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float
     float* Xs = smem;                        // [CIC][ID][IH][RS]
     float* Ws = smem + Cfg::XS_FLOATS;       // 2 x [27][CIC][COP]
 
-    int bid = blockIdx.x;
+    int bid = ecm_xcd_tile(blockIdx.x, gridDim.x);       // one contiguous run of tiles per XCD (its own L2), see common.h
     const int tw = bid % tiles_w; bid /= tiles_w;
     const int th = bid % tiles_h; bid /= tiles_h;
     const int td = bid % tiles_d;

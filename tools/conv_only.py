@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wgrad|costvol] [B]"""
+"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wgrad|gn|costvol] [B]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,6 +15,13 @@ if which == "conv":
 elif which == "wgrad":
     x = torch.randn(B, 32, 48, 144, 240, device=dev); gy = torch.randn(B, 32, 48, 144, 240, device=dev)
     for _ in range(5): g = ops._wgrad(x, gy, 32, 32, 1)
+elif which == "gn":
+    x = torch.randn(B, 32, 48, 144, 240, device=dev, requires_grad=True)
+    gm, bt = torch.ones(32, device=dev, requires_grad=True), torch.zeros(32, device=dev, requires_grad=True)
+    G = torch.randn(B, 32, 48, 144, 240, device=dev)
+    for _ in range(3):
+        y = ops.group_norm_act(x, gm, bt, None, True)
+        torch.autograd.grad(y, x, G)
 elif which == "costvol":
     L, R = torch.randn(B, 32, 144, 240, device=dev), torch.randn(B, 32, 144, 240, device=dev)
     for _ in range(5): c = ops.cost_volume(L, R, 48)

@@ -213,7 +213,9 @@ def main():
                 pm = json.load(f)
             if (H, W, D) == (576, 960, 192):
                 traffic_cv = pm["costvol_fwd_v4"]["hbm_bytes_per_launch_B1"] * B
-                traffic_conv = pm["conv3d_k3_mfma<1,1,4,8,4> 32->32"]["hbm_bytes_per_launch_B1"] * B
+                cv_pm = pm["conv3d_k3_mfma<1,1,4,8,4> 32->32"]
+                traffic_conv = cv_pm["hbm_bytes_per_launch_B4_xcd_aware"] if B == 4 and "hbm_bytes_per_launch_B4_xcd_aware" in cv_pm \
+                    else cv_pm["hbm_bytes_per_launch_B1"] * B
         except (OSError, KeyError, ValueError):
             pass
         shape_name = {(576, 960): "SceneFlow 960x540 (padded to 576)",

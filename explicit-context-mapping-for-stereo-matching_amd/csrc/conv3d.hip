@@ -28,9 +28,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TW = 32;
 
-template <int CO_TILES, int STRIDE, int TD, int TH, int CIC>
+// KD = 3: the 3x3x3 Conv3d.  KD = 1: a 3x3 Conv2d as a depth-1 volume with no taps / padding along depth (the encoder's
+// 32- and 64-channel convbn layers, cmfsm.py:37-47): same kernel, 9 taps.
+template <int CO_TILES, int STRIDE, int TD, int TH, int CIC, int KD = 3>
 struct ConvCfg {
-    static constexpr int ID = (TD - 1) * STRIDE + 3;
+    static constexpr int NTAPS = 9 * KD;
+    static constexpr int ID = (TD - 1) * STRIDE + KD;
     static constexpr int IH = (TH - 1) * STRIDE + 3;
     static constexpr int IW = (TW - 1) * STRIDE + 3;
     static constexpr int RS = IW;                       // LDS row stride (floats)
@@ -38,19 +41,19 @@ struct ConvCfg {
     static constexpr int NT = ROWS / 4;                 // rows per wave
     static constexpr int COP = CO_TILES * 32;
     static constexpr int XS_FLOATS = CIC * ID * IH * RS;
-    static constexpr int WS_FLOATS = 27 * CIC * COP;
+    static constexpr int WS_FLOATS = NTAPS * CIC * COP;
     static constexpr int LDS_BYTES = (XS_FLOATS + 2 * WS_FLOATS) * 4;     // weight slice is double-buffered (LDS-DMA)
     static_assert(ROWS % 4 == 0, "rows must split over 4 waves");
     static_assert((NT <= TH && TH % NT == 0) || (NT % TH == 0), "wave rows must tile (dz,hy) statically");
     static_assert(CIC % 2 == 0, "k-step is 2 channels");
 };
 
-template <int CO_TILES, int STRIDE, int TD, int TH, int CIC>
+template <int CO_TILES, int STRIDE, int TD, int TH, int CIC, int KD = 3>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                       float* __restrict__ y, int Ci, int Co, int D, int H, int W,
                                                       int Do, int Ho, int Wo, int tiles_d, int tiles_h, int tiles_w) {
-    using Cfg = ConvCfg<CO_TILES, STRIDE, TD, TH, CIC>;
-    constexpr int ID = Cfg::ID, IH = Cfg::IH, IW = Cfg::IW, RS = Cfg::RS, NT = Cfg::NT, COP = Cfg::COP;
+    using Cfg = ConvCfg<CO_TILES, STRIDE, TD, TH, CIC, KD>;
+    constexpr int ID = Cfg::ID, IH = Cfg::IH, IW = Cfg::IW, RS = Cfg::RS, NT = Cfg::NT, COP = Cfg::COP, NTAPS = Cfg::NTAPS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [CIC][ID][IH][RS]
     float* Ws = smem + Cfg::XS_FLOATS;      // 2 x [27][CIC][COP]
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
     const int th = bid % tiles_h;
     const int b = bid / tiles_h;
     const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
-    const int id0 = od0 * STRIDE - 1, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
+    const int id0 = od0 * STRIDE - KD / 2, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
     constexpr int NPOS = ID * IH * IW;
     constexpr int PP = (NPOS + 255) / 256;                         // positions per thread
     constexpr int NX = CIC * PP;
-    constexpr int NWQ = (27 * CIC * COP / 4 + 255) / 256;          // weight float4s per thread
+    constexpr int NWQ = (NTAPS * CIC * COP / 4 + 255) / 256;       // weight float4s per thread
     float xr[NX];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
 #pragma unroll
         for (int i = 0; i < NWQ; ++i) {
             const int e = tid + i * 256;
-            if (e < 27 * CIC * COP / 4) {
+            if (e < NTAPS * CIC * COP / 4) {
                 const int tap = e / (CIC * COP / 4), r = e - tap * (CIC * COP / 4);
                 const float* src = wp + ((size_t)tap * Ci + c0) * COP + (size_t)r * 4;
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wdst + (wave_u * 64 + i * 256) * 4), 16, 0, 0);
@@ -160,9 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
         CV_T(4);
         // ---- 27 * CIC/2 k-steps ---------------------------------------------------------------
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-            constexpr int dummy = 0; (void)dummy;
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int kd = KD == 3 ? tap / 9 : 0, kh = (tap / 3) % 3, kw = tap % 3;
 #pragma unroll
             for (int kk = 0; kk < CIC / 2; ++kk) {
                 float a[CO_TILES];
@@ -211,30 +213,30 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
 // Conv3d weight [Co,Ci,27] -> [27][Ci][COP] (zero padded co), or the dgrad operator:
 // w'[ci][co][26-tap] viewed as a conv with Cin'=Co, Cout'=Ci -> packed[tap'][co][CiP].
 __global__ void pack_conv_weight(const float* __restrict__ w, float* __restrict__ packed, int Co, int Ci, int cop,
-                                 int flip_transpose) {
+                                 int flip_transpose, int taps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int Kin = flip_transpose ? Co : Ci;       // input channels of the packed operator
     const int Kout = flip_transpose ? Ci : Co;
-    if (i >= 27 * Kin * cop) return;
+    if (i >= taps * Kin * cop) return;
     const int o = i % cop;
     const int k = (i / cop) % Kin;
     const int tap = i / (cop * Kin);
     float v = 0.f;
     if (o < Kout) {
-        if (!flip_transpose) v = w[((size_t)o * Ci + k) * 27 + tap];
-        else v = w[((size_t)k * Ci + o) * 27 + (26 - tap)];
+        if (!flip_transpose) v = w[((size_t)o * Ci + k) * taps + tap];
+        else v = w[((size_t)k * Ci + o) * taps + (taps - 1 - tap)];
     }
     packed[i] = v;
 }
 
-template <int CO_TILES, int STRIDE, int TD, int TH, int CIC>
+template <int CO_TILES, int STRIDE, int TD, int TH, int CIC, int KD = 3>
 int launch_conv(const float* x, const float* wp, float* y, int B, int Ci, int Co, int D, int H, int W, hipStream_t st) {
-    using Cfg = ConvCfg<CO_TILES, STRIDE, TD, TH, CIC>;
+    using Cfg = ConvCfg<CO_TILES, STRIDE, TD, TH, CIC, KD>;
     const int Do = (D - 1) / STRIDE + 1, Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
     const int tiles_d = (Do + TD - 1) / TD, tiles_h = (Ho + TH - 1) / TH, tiles_w = (Wo + TW - 1) / TW;
     const long long nblk = (long long)B * tiles_d * tiles_h * tiles_w;
     if (nblk > 0x7fffffffLL || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
-    auto kern = conv3d_k3_mfma<CO_TILES, STRIDE, TD, TH, CIC>;
+    auto kern = conv3d_k3_mfma<CO_TILES, STRIDE, TD, TH, CIC, KD>;
     {
         const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -257,8 +259,33 @@ extern "C" int ecm_conv3d_pack_weight(const float* w, float* packed, int Co, int
     const int cop = ((Kout + 31) / 32) * 32;
     const int n = 27 * Kin * cop;
     hipLaunchKernelGGL(pack_conv_weight, dim3((n + 255) / 256), dim3(256), 0, ecm_stream(stream), w, packed, Co, Ci, cop,
-                       flip_transpose);
+                       flip_transpose, 27);
     return ECM_LAUNCH_RESULT();
+}
+
+// ---- 3x3 Conv2d, stride 1, pad 1 (the encoder's 32/64-channel layers): depth-1 volume, 9 taps -----------------------
+extern "C" long long ecm_conv2d_packed_floats(int Ci, int Co) {
+    const long long cop = ((Co + 31) / 32) * 32;
+    return 9LL * Ci * cop;
+}
+
+extern "C" int ecm_conv2d_pack_weight(const float* w, float* packed, int Co, int Ci, int flip_transpose, void* stream) {
+    ECM_CHECK_ARG(w && packed && Co > 0 && Ci > 0);
+    const int Kin = flip_transpose ? Co : Ci, Kout = flip_transpose ? Ci : Co;
+    const int cop = ((Kout + 31) / 32) * 32;
+    const int n = 9 * Kin * cop;
+    hipLaunchKernelGGL(pack_conv_weight, dim3((n + 255) / 256), dim3(256), 0, ecm_stream(stream), w, packed, Co, Ci, cop,
+                       flip_transpose, 9);
+    return ECM_LAUNCH_RESULT();
+}
+
+extern "C" int ecm_conv2d_k3_fwd(const float* x, const float* wpacked, float* y, int B, int Ci, int Co, int H, int W,
+                                 void* stream) {
+    ECM_CHECK_ARG(x && wpacked && y && B > 0 && H > 0 && W > 0);
+    if (Ci % 8 != 0 || Co < 1 || Co > 64) return ECM_EUNSUP;
+    hipStream_t st = ecm_stream(stream);
+    if (Co <= 32) return launch_conv<1, 1, 1, 32, 4, 1>(x, wpacked, y, B, Ci, Co, 1, H, W, st);
+    return launch_conv<2, 1, 1, 16, 8, 1>(x, wpacked, y, B, Ci, Co, 1, H, W, st);
 }
 
 extern "C" int ecm_conv3d_k3_fwd(const float* x, const float* wpacked, float* y, int B, int Ci, int Co, int D, int H,

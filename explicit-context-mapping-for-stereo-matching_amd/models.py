@@ -61,8 +61,10 @@ class HipReLU(nn.ReLU):
 
 
 class EncConv2d(nn.Conv2d):
-    """nn.Conv2d of the encoder.  Forward / data gradient: PyTorch-ROCm (MIOpen).  For the 3x3, stride-1, undilated
-    layers with 32 or 64 channels on both sides the weight gradient runs on the MFMA wgrad kernel (ops.Conv2dK3)."""
+    """nn.Conv2d of the encoder.  The 3x3, stride-1, undilated layers with 32 or 64 channels on both sides take their
+    weight gradient from the MFMA wgrad kernel, and the 32 -> 32 ones also forward and data gradient from the MFMA
+    implicit-GEMM kernel (ops.Conv2dK3); every other layer -- the 3-channel stem, the stride-2 and dilated layers, the
+    128-channel stages, 1x1 convolutions -- stays on PyTorch-ROCm (MIOpen)."""
 
     def _hip_wgrad(self):
         return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation == (1, 1)
@@ -70,7 +72,7 @@ class EncConv2d(nn.Conv2d):
                 and self.in_channels in (32, 64) and self.out_channels in (32, 64))
 
     def forward(self, x):
-        if self._hip_wgrad() and x.is_cuda and torch.is_grad_enabled() and self.weight.requires_grad:
+        if self._hip_wgrad() and x.is_cuda:
             return ops.conv2d_k3(x, self.weight)
         return super().forward(x)
 

@@ -484,15 +484,41 @@ def _dgrad_small_co(gy, w):
     return _conv_fwd(gyp, _pack_conv(wp, True), Ci, 1)
 
 
+def _pack_conv2d(w, flip_transpose=False):
+    Co, Ci = w.shape[:2]
+    kin, kout = (Co, Ci) if flip_transpose else (Ci, Co)
+    packed = torch.empty(_lib.query("ecm_conv2d_packed_floats", kin, kout), device=w.device, dtype=w.dtype)
+    _lib.call("ecm_conv2d_pack_weight", _p(_c(w)), _p(packed), Co, Ci, int(flip_transpose), _stream())
+    return packed
+
+
+def _conv2d_fwd(x, packed, Co):
+    B, Ci, H, W = x.shape
+    y = torch.empty(B, Co, H, W, device=x.device, dtype=x.dtype)
+    _lib.call("ecm_conv2d_k3_fwd", _p(x), _p(packed), _p(y), B, Ci, Co, H, W, _stream())
+    return y
+
+
+def _conv2d_native(w):
+    """Layers whose forward / data gradient run on the MFMA kernel: the full- and half-resolution 32 -> 32 stack, where it
+    beats MIOpen's Winograd (576x960 x 8 images: 0.75 / 0.72 ms vs 0.82 / 0.84 ms; 288x480: equal).  The 64-channel layers
+    at 144x240 give only ~1.1 rounds of workgroups and stay on MIOpen (0.20 ms vs 0.22 ms), like everything wider
+    (tools/miopen_conv2d_probe.py, profiles/r01e_miopen_conv2d_probe.txt)."""
+    return w.shape[0] == 32 and w.shape[1] == 32
+
+
 class Conv2dK3(torch.autograd.Function):
-    """The encoder's 3x3 / stride 1 / pad 1 Conv2d (convbn, cmfsm.py:37-47): forward and data gradient stay on
-    PyTorch-ROCm (MIOpen, as for the rest of the encoder); the weight gradient -- where MIOpen's fp32 kernels reach
-    45-77 TFLOP/s on these shapes -- runs on the MFMA wgrad kernel (depth-1 volume, 9 taps)."""
+    """The encoder's 3x3 / stride 1 / pad 1 Conv2d (convbn, cmfsm.py:37-47).  Weight gradient: the MFMA wgrad kernel
+    (depth-1 volume, 9 taps), where MIOpen's fp32 kernels reach 45-77 TFLOP/s.  Forward and data gradient: the MFMA
+    implicit-GEMM kernel for the 32 -> 32 layers (see _conv2d_native), MIOpen otherwise (e.g. the 64-channel layers and
+    the 15*32-channel class convolution of costvol_conv3d)."""
 
     @staticmethod
     def forward(ctx, x, w):
         _chk(x, w)
         ctx.save_for_backward(x, w)
+        if _conv2d_native(w):
+            return _conv2d_fwd(_c(x), _pack_conv2d(w), w.shape[0])
         return torch.nn.functional.conv2d(x, w, None, 1, 1, 1)
 
     @staticmethod
@@ -500,8 +526,11 @@ class Conv2dK3(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                     (True, False, False))[0]
+            if _conv2d_native(w):
+                gx = _conv2d_fwd(_c(gy), _pack_conv2d(w, True), w.shape[1])
+            else:
+                gx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (True, False, False))[0]
         if ctx.needs_input_grad[1]:
             xc, gc = _c(x), _c(gy)
             B, Ci, H, W = xc.shape

@@ -47,7 +47,10 @@ for ci, co, k, st, dil, (H, W), cnt in SHAPES:
     if k == 3 and st == 1 and dil == 1 and ci in (32, 64) and co in (32, 64):
         yy = ops.conv2d_k3(x.detach(), w)          # x without grad: time the weight gradient alone
         th = timeit(lambda: torch.autograd.grad(yy, w, g, retain_graph=True))
-        mine = f" | HIP wgrad {th:6.3f} ms {gf / th:6.1f} TF"
+        pk, pkt = ops._pack_conv2d(w.detach()), ops._pack_conv2d(w.detach(), True)
+        tff = timeit(lambda: ops._conv2d_fwd(x.detach(), pk, co))
+        tdd = timeit(lambda: ops._conv2d_fwd(g, pkt, ci))
+        mine = f" | HIP fwd {tff:6.3f} ms {gf / tff:6.1f} TF, dgrad {tdd:6.3f} ms {gf / tdd:6.1f} TF, wgrad {th:6.3f} ms {gf / th:6.1f} TF"
     print(f"{ci:3d}->{co:3d} s{st} d{dil} {H}x{W} x{cnt:2d}: fwd {tf:6.3f} ms {gf / tf:6.1f} TF | dgrad {td:6.3f} ms {gf / td:6.1f} TF"
           f" | wgrad {tw:6.3f} ms {gf / tw:6.1f} TF" + mine, flush=True)
     del x, w, y, g

@@ -61,10 +61,9 @@ class HipReLU(nn.ReLU):
 
 
 class EncConv2d(nn.Conv2d):
-    """nn.Conv2d of the encoder.  The 3x3, stride-1, undilated layers with 32 or 64 channels on both sides take their
-    weight gradient from the MFMA wgrad kernel, and the 32 -> 32 ones also forward and data gradient from the MFMA
-    implicit-GEMM kernel (ops.Conv2dK3); every other layer -- the 3-channel stem, the stride-2 and dilated layers, the
-    128-channel stages, 1x1 convolutions -- stays on PyTorch-ROCm (MIOpen)."""
+    """nn.Conv2d of the encoder.  The 3x3, stride-1, undilated layers with 32 or 64 channels on both sides run on the
+    MFMA kernels (forward, data gradient and weight gradient: ops.Conv2dK3); every other layer -- the 3-channel stem, the
+    stride-2 and dilated layers, the 128-channel stages, 1x1 convolutions -- stays on PyTorch-ROCm (MIOpen)."""
 
     def _hip_wgrad(self):
         return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation == (1, 1)

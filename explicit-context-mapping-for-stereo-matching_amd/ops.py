@@ -500,18 +500,18 @@ def _conv2d_fwd(x, packed, Co):
 
 
 def _conv2d_native(w):
-    """Layers whose forward / data gradient run on the MFMA kernel: the full- and half-resolution 32 -> 32 stack, where it
-    beats MIOpen's Winograd (576x960 x 8 images: 0.75 / 0.72 ms vs 0.82 / 0.84 ms; 288x480: equal).  The 64-channel layers
-    at 144x240 give only ~1.1 rounds of workgroups and stay on MIOpen (0.20 ms vs 0.22 ms), like everything wider
-    (tools/miopen_conv2d_probe.py, profiles/r01e_miopen_conv2d_probe.txt)."""
-    return w.shape[0] == 32 and w.shape[1] == 32
+    """Layers whose forward / data gradient run on the MFMA kernel: 32 or 64 channels on both sides, where it is level with
+    or ahead of MIOpen's Winograd (8 images: 32->32 at 576x960 0.75 / 0.72 ms vs 0.82 / 0.84 ms; 64->64 at 144x240 0.186 ms
+    vs 0.200 ms; tools/miopen_conv2d_probe.py).  Wider layers, the 3-channel stem and the class convolutions of
+    costvol_conv3d stay on MIOpen."""
+    return w.shape[0] in (32, 64) and w.shape[1] in (32, 64)
 
 
 class Conv2dK3(torch.autograd.Function):
     """The encoder's 3x3 / stride 1 / pad 1 Conv2d (convbn, cmfsm.py:37-47).  Weight gradient: the MFMA wgrad kernel
     (depth-1 volume, 9 taps), where MIOpen's fp32 kernels reach 45-77 TFLOP/s.  Forward and data gradient: the MFMA
-    implicit-GEMM kernel for the 32 -> 32 layers (see _conv2d_native), MIOpen otherwise (e.g. the 64-channel layers and
-    the 15*32-channel class convolution of costvol_conv3d)."""
+    implicit-GEMM kernel for the 32/64-channel layers (see _conv2d_native), MIOpen otherwise (e.g. the 15*32-channel class
+    convolution of costvol_conv3d)."""
 
     @staticmethod
     def forward(ctx, x, w):

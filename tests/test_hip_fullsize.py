@@ -35,7 +35,8 @@ def test_cost_volume_full_size_exact(ecm, name):
     ecm.ops.cost_volume(Lg, Rg, 48).backward(G)
     lhs = (cost.double() * G.double()).sum()
     rhs = (L.double() * Lg.grad.double()).sum() + (R.double() * Rg.grad.double()).sum()
-    assert abs(lhs - rhs) <= 1e-6 * abs(lhs) + 1e-3
+    # 4.7e8 fp32 terms on the left, gradients accumulated in fp32 on the right: rounding alone is ~ sqrt(N) * eps ~ 1e-3
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs) + 5e-3
 
 
 @pytest.mark.parametrize("name,ci,co,stride", [("sceneflow", 32, 32, 1), ("sceneflow", 32, 64, 2), ("sceneflow", 32, 1, 1),

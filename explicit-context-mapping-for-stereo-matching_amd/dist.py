@@ -78,20 +78,10 @@ class FlatBucketDDP:
 
 def masked_smooth_l1_x3(preds, gt, maxdisp: int = 192):
     """The reference's training loss (train.py:162,168-174): mask 0<d<maxdisp, smooth-L1 'mean' over the masked pixels
-    of each head, weights 0.5/0.7/1.0.  On the GPU this is the fused HIP loss kernel (ops.stereo_loss3: one pass, no
-    `o[mask]` gathers and their six device->host syncs per step); CPU tensors (the gloo tests) take the same arithmetic
-    in plain torch."""
-    if gt.is_cuda:
-        from . import ops
-        return ops.stereo_loss3(preds, gt, maxdisp)[0]
-    import torch.nn.functional as F
-    mask = (gt < maxdisp) & (gt > 0)
-    cnt = mask.sum().to(gt.dtype)
-    total = 0.0
-    for wgt, p in zip((0.5, 0.7, 1.0), preds):
-        per = F.smooth_l1_loss(p.squeeze(1), gt, reduction="none")
-        total = total + wgt * (torch.where(mask, per, torch.zeros_like(per)).sum() / cnt)
-    return total
+    of each head, weights 0.5/0.7/1.0 -- the fused HIP loss kernel (ops.stereo_loss3: one pass, no `o[mask]` gathers and
+    their six device->host syncs per step).  GPU tensors only, like every op of the package (no CPU fallback)."""
+    from . import ops
+    return ops.stereo_loss3(preds, gt, maxdisp)[0]
 
 
 class GraphedForward:

@@ -71,8 +71,8 @@ class EncConv2d(nn.Conv2d):
                 and self.in_channels in (32, 64) and self.out_channels in (32, 64))
 
     def forward(self, x):
-        if self._hip_wgrad() and x.is_cuda:
-            return ops.conv2d_k3(x, self.weight)
+        if self._hip_wgrad():
+            return ops.conv2d_k3(x, self.weight)          # raises on CPU tensors, like every op of the package
         return super().forward(x)
 
 

@@ -12,7 +12,7 @@ Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
 
 Parity pinning: every function here is checked against outputs of the
 reference's own code (imported in the build container by
-`tools/make_golden.py` / `tools/make_golden_archs.py`) stored under
+`tests/golden/make_golden.py` / `tests/golden/make_golden_archs.py`) stored under
 `tests/golden/*.npz`; see `tests/test_oracle_golden.py`.  A second,
 ATen-free restatement in plain C (`oracle/ecm_oracle_c.c`, naive loops) is
 checked against the same fixtures in `tests/test_oracle_c.py`.

@@ -3,7 +3,7 @@
 
 Runs only in the build container (needs /root/reference); the fixtures it
 writes are data (inputs are regenerated from seeds, outputs are stored) and are
-what travels to the GPU box.  Usage:  python -B tools/make_golden.py
+what travels to the GPU box.  Usage:  python -B tests/golden/make_golden.py
 
 Import recipe: the reference imports torchvision and a
 protobuf-3-era caffe_pb2 at import time and calls .cuda() unconditionally;
@@ -17,7 +17,7 @@ import sys
 import types
 
 sys.dont_write_bytecode = True
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import numpy as np

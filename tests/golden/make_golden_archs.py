@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden fixtures for the OTHER registered architectures (cmfsm_sub_8/16, cm_sub_4/8/16, bilinear_cmf[_sub_8/16]):
 parameter contracts (state_dict key -> shape) and the whole post-encoder path on tiny feature maps, produced by the
-REFERENCE's own forward() behind a stub encoder.  Build container only.  Usage: python -B tools/make_golden_archs.py"""
+REFERENCE's own forward() behind a stub encoder.  Build container only.  Usage: python -B tests/golden/make_golden_archs.py"""
 from __future__ import annotations
 
 import json
@@ -10,7 +10,7 @@ import sys
 import types
 
 sys.dont_write_bytecode = True
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

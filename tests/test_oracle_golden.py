@@ -1,5 +1,5 @@
 """The CPU oracle (oracle/ecm_oracle.py) against golden vectors produced by the reference's own code
-(tools/make_golden.py).  Pins the oracle before anything is compared with it."""
+(tests/golden/make_golden.py).  Pins the oracle before anything is compared with it."""
 import torch
 
 from conftest import load_golden

@@ -149,6 +149,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timers = lib.disable_timers()
+    last = step()                                          # outside the timed region: the result must be finite
+    assert bool(torch.isfinite(last).all()), "non-finite loss / disparity after the timed steps"
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

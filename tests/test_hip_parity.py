@@ -461,6 +461,17 @@ def test_frame_prep_train_crop_bit_exact(ecm):
         assert torch.equal(d[b].cpu(), Dp) and torch.equal(im[b].cpu(), I)
 
 
+def test_frame_prep_large_batch(ecm):
+    """More samples than one launch carries crop origins for (32): the launcher splits the batch."""
+    fr = _frames(35, 260, 516, 9)
+    y0 = [i % 5 for i in range(35)]
+    x0 = [(3 * i) % 5 for i in range(35)]
+    l, r, d = ecm.ops.frame_prep(dev(fr), y0, x0, 256, 512)
+    for b in (0, 31, 32, 34):
+        L, R, Dp, _ = O.flying3d_sample(fr[b].numpy(), "train", (y0[b], x0[b]))
+        assert torch.equal(l[b].cpu(), L) and torch.equal(r[b].cpu(), R) and torch.equal(d[b].cpu(), Dp)
+
+
 def test_frame_prep_eval_pad_bit_exact(ecm):
     """Eval split: rows [0,540) then the frame's last 36 rows again (576 rows), 960 columns."""
     fr = _frames(2, 540, 960, 6)

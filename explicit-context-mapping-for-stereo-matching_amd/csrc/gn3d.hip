@@ -176,15 +176,15 @@ __global__ void gn_bwd_final_chan(const float* __restrict__ part, float* __restr
     chan[2 * i + 1] = (float)q;
 }
 
-// ggamma[c] += sum_b chan[b,c].sgx ; gbeta[c] += sum_b chan[b,c].sg      (one thread per c)
+// ggamma[c] = sum_b chan[b,c].sgx ; gbeta[c] = sum_b chan[b,c].sg      (one thread per c)
 __global__ void gn_bwd_params(const float* __restrict__ chan, float* __restrict__ ggamma, float* __restrict__ gbeta,
                               int B, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float sg = 0.f, sgx = 0.f;
     for (int b = 0; b < B; ++b) { sg += chan[(b * C + c) * 2]; sgx += chan[(b * C + c) * 2 + 1]; }
-    ggamma[c] += sgx;
-    gbeta[c] += sg;
+    ggamma[c] = sgx;
+    gbeta[c] = sg;
 }
 
 // gx = rstd * (g*gamma - s1/n - xhat*s2/n),  s1 = sum_{c in group} gamma_c sg_c,  s2 = sum gamma_c sgx_c

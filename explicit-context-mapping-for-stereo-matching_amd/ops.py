@@ -613,8 +613,7 @@ class GroupNormAct(torch.autograd.Function):
         gskip = _empty_like(x) if ctx.has_skip else None
         if ctx.has_skip and not ctx.relu:
             gskip = gy                      # no mask: the skip gradient is gy itself
-        ggamma = torch.zeros_like(gamma)
-        gbeta = torch.zeros_like(gamma)
+        ggamma, gbeta = _empty_like(gamma), _empty_like(gamma)
         nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
         scratch = _scratch(nb, x.device)
         _lib.call("ecm_gn3d_bwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(gy), _p(gx),

@@ -172,7 +172,7 @@ int ecm_gn3d_stats(const float* x, float* mean_rstd, void* scratch, long long sc
                    int B, int C, long long S, float eps, void* stream);
 int ecm_gn3d_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
                    const float* skip, float* y, int B, int C, long long S, int relu, void* stream);
-/* Backward of y = relu?(gn(x) + skip): writes gx and gskip (NULL to skip it); ACCUMULATES into ggamma[C], gbeta[C].
+/* Backward of y = relu?(gn(x) + skip): writes gx, gskip (NULL to skip it), ggamma[C] and gbeta[C].
  * ReLU mask (relu != 0): from the forward OUTPUT y when y != NULL; with y == NULL it is recomputed from x, which needs
  * beta and is only valid for a forward WITHOUT skip (saves one tensor read per pass).  beta may be NULL otherwise. */
 int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,

@@ -122,6 +122,75 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1_fwd(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ data gradient
+// gx[b,ci,d,h,w] = sum_tap w[ci,tap] * gy[b, d-kd+1, h-kh+1, w-kw+1]: 27 values of the single-channel gy per voxel fan out
+// to all Ci channels.  Store-bound (Ci x the volume is written, gy is 1/Ci of that): one workgroup stages a 3 x (DTH+2) x
+// (DTW+2) gy halo tile in LDS, every thread keeps the 27 neighbours of its 4 consecutive voxels in registers (54 LDS
+// reads) and streams out one float4 per channel; the weights come through the scalar cache.
+constexpr int DTH = 8, DTW = 128;                         // output tile of one depth plane: 8 rows x 128 columns
+constexpr int DGW = DTW + 4;                              // halo row stride (1 left, 1 right, +2 so rows stay 4-aligned)
+
+__global__ __launch_bounds__(256) void conv3d_c1_dgrad(const float* __restrict__ gy, const float* __restrict__ w,
+                                                       float* __restrict__ gx, int Ci, int D, int H, int W, int tiles_h,
+                                                       int tiles_w) {
+    __shared__ float Gs[3 * (DTH + 2) * DGW];
+    int bid = blockIdx.x;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h; bid /= tiles_h;
+    const int d = bid % D;
+    const int b = bid / D;
+    const int h0 = th * DTH, w0 = tw * DTW;
+    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
+    const float* gb = gy + (size_t)b * DHW;
+    for (int e = threadIdx.x; e < 3 * (DTH + 2) * (DTW + 2); e += 256) {
+        const int xx = e % (DTW + 2), r = e / (DTW + 2);
+        const int hy = r % (DTH + 2), dz = r / (DTH + 2);
+        const int gz = d - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + xx;
+        float v = 0.f;
+        if ((unsigned)gz < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+            v = gb[(size_t)gz * HW + (size_t)gh * W + gw];
+        Gs[(dz * (DTH + 2) + hy) * DGW + xx] = v;
+    }
+    __syncthreads();
+    const int hy = threadIdx.x >> 5, x4 = (threadIdx.x & 31) * 4;
+    const int oh = h0 + hy, ow = w0 + x4;
+    if (oh >= H || ow >= W) return;
+    // g[j][i]: row j = dz*3 + hh of the 3 x 3 neighbourhood rows, i = 0..5 the columns ow-1 .. ow+4 (halo coordinates x4 .. x4+5)
+    float g[9][6];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g[j][i] = Gs[((j / 3) * (DTH + 2) + hy + (j % 3)) * DGW + x4 + i];
+    const bool full = ow + 3 < W && (W & 3) == 0;
+    float* op = gx + (size_t)b * Ci * DHW + (size_t)d * HW + (size_t)oh * W + ow;
+    for (int ci = 0; ci < Ci; ++ci) {
+        const float* wc = w + (size_t)ci * 27;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    // gy index d-kd+1 -> halo plane (2-kd); h-kh+1 -> halo row offset (2-kh); w-kw+1 -> column offset (2-kw)
+                    const float wv = wc[kd * 9 + kh * 3 + kw];
+                    const int j = (2 - kd) * 3 + (2 - kh), i0 = 2 - kw;
+                    a0 = fmaf(wv, g[j][i0 + 0], a0);
+                    a1 = fmaf(wv, g[j][i0 + 1], a1);
+                    a2 = fmaf(wv, g[j][i0 + 2], a2);
+                    a3 = fmaf(wv, g[j][i0 + 3], a3);
+                }
+        float* o = op + (size_t)ci * DHW;
+        if (full) *reinterpret_cast<float4*>(o) = make_float4(a0, a1, a2, a3);
+        else {
+            o[0] = a0;
+            if (ow + 1 < W) o[1] = a1;
+            if (ow + 2 < W) o[2] = a2;
+            if (ow + 3 < W) o[3] = a3;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 constexpr int GTD = 2, GTH = 8, GTW = 32, GNV = GTD * GTH * GTW;       // 512 voxels of x per tile (no halo on x)
 constexpr int GXSTR = GNV + 1;                                           // odd channel stride: 32 lanes (ci) -> 32 banks
@@ -297,6 +366,16 @@ extern "C" int ecm_conv3d_c1_fwd(const float* x, const float* w, float* y, int B
     }
     hipLaunchKernelGGL(conv3d_c1_fwd, dim3((unsigned)nblk), dim3(256), M_LDS_BYTES, ecm_stream(stream), x, w, y, Ci, D, H, W,
                        zchunk, tiles_z, tiles_h, tiles_w);
+    return ECM_LAUNCH_RESULT();
+}
+
+extern "C" int ecm_conv3d_c1_dgrad(const float* gy, const float* w, float* gx, int B, int Ci, int D, int H, int W, void* stream) {
+    ECM_CHECK_ARG(gy && w && gx && B > 0 && Ci > 0 && D > 0 && H > 0 && W > 0);
+    const int tiles_h = (H + DTH - 1) / DTH, tiles_w = (W + DTW - 1) / DTW;
+    const long long nblk = (long long)B * D * tiles_h * tiles_w;
+    if (nblk > 0x7fffffffLL) return ECM_EUNSUP;
+    hipLaunchKernelGGL(conv3d_c1_dgrad, dim3((unsigned)nblk), dim3(256), 0, ecm_stream(stream), gy, w, gx, Ci, D, H, W, tiles_h,
+                       tiles_w);
     return ECM_LAUNCH_RESULT();
 }
 

@@ -450,7 +450,11 @@ class Conv3dK3(torch.autograd.Function):
         Co, Ci = w.shape[0], w.shape[1]
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            if ctx.stride == 1:
+            if _is_c1(w, ctx.stride):
+                gx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+                _lib.call("ecm_conv3d_c1_dgrad", _p(gy), _p(w), _p(gx), x.shape[0], Ci, x.shape[2], x.shape[3], x.shape[4],
+                          _stream())
+            elif ctx.stride == 1:
                 gx = _conv_fwd(gy, _pack_conv(w, True), Ci, 1) if Co % 4 == 0 else _dgrad_small_co(gy, w)
             else:
                 gx = _deconv_fwd(gy, _pack_deconv(w), Ci, x.shape[2:])

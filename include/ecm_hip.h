@@ -126,6 +126,8 @@ int ecm_conv3d_k3_fwd(const float* x, const float* wpacked, float* y,
 /* The classifier's last layer Conv3d(Ci<=32 -> 1) (cmfsm.py:624,629,634) on its own kernels: w is the reference weight
  * [1,Ci,3,3,3] (no packing); y: [B,1,D,H,W].  wgrad: gw [1,Ci,27] from x [B,Ci,D,H,W] and gy [B,1,D,H,W]. */
 int ecm_conv3d_c1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, void* stream);
+/* data gradient of the same layer: gx[B,Ci,D,H,W] from gy[B,1,D,H,W] and w[1,Ci,27] (any Ci). */
+int ecm_conv3d_c1_dgrad(const float* gy, const float* w, float* gx, int B, int Ci, int D, int H, int W, void* stream);
 long long ecm_conv3d_c1_wgrad_scratch_bytes(int B, int Ci, int D, int H, int W);
 int ecm_conv3d_c1_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
                         int B, int Ci, int D, int H, int W, void* stream);

@@ -57,6 +57,9 @@ PROTOTYPES = {
     "ecm_costvol_conv_assemble_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ecm_costvol_conv_assemble_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ecm_frame_prep": (_I, [_P] * 5 + [_I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "ecm_gn3d_cluster_mode": (_I, [_I]),
+    "ecm_gn3d_poll_ms": (_I, [_I]),
+    "ecm_async_status": (_I, [_I]),
     "ecm_gn3d_scratch_bytes": (_LL, [_I, _I, _LL]),
     "ecm_gn3d_stats": (_I, [_P, _P, _P, _LL, _I, _I, _LL, _F, _P]),
     "ecm_gn3d_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _LL, _I, _P]),

@@ -3,6 +3,7 @@
 // HBM-bound: stats = 1 read of x; apply = 1 read (+1 skip read) + 1 write; all float4, grid-strided.
 // Deterministic: two-stage reductions through caller-provided scratch, no float atomics.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -254,7 +255,6 @@ __global__ __launch_bounds__(THREADS) void gn_bwd_apply(const float* __restrict_
 // The grid never exceeds what is resident at once (occupancy query), so the collect cannot deadlock; a bounded
 // spin turns a lost workgroup into NaN statistics instead of a hang.  Shapes that do not fit (S % 4, spans larger
 // than the register capacity of 256 workgroups) take the two-stage path.
-constexpr int FUSED_MAX_CL = 256;
 constexpr int FUSED_MAX_CPG = 8;
 #ifndef ECM_GN_FWD_MAXV4
 #define ECM_GN_FWD_MAXV4 32       // measured on MI355X (tools/gn_bench.py, B=4 x 32 x 48x144x240): 32@2 / 20@2 -> fwd 0.344 ms,
@@ -297,25 +297,58 @@ __device__ __forceinline__ void slot_publish(unsigned long long* slot, float s, 
     const unsigned long long v = ((unsigned long long)__float_as_uint(q) << 32) | (unsigned long long)__float_as_uint(s);
     __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Poll until the slot is filled (bounded: a workgroup that never ran turns into NaN results, not a hang).
-__device__ __forceinline__ bool slot_collect(const unsigned long long* slot, float& s, float& q) {
+// Poll until the slot is filled.  Bounded by WALL TIME (s_memrealtime: 100 MHz, constant): a cluster member that never
+// became resident within `poll_ticks` turns into NaN results AND a sticky error word the host reports (ECM_EASYNC) --
+// never into a hang, never into a silent rc 0.
+__device__ __forceinline__ bool slot_collect(const unsigned long long* slot, float& s, float& q, unsigned long long poll_ticks) {
     unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    while (v == SLOT_EMPTY) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 23)) break;
-        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v == SLOT_EMPTY) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int spins = 0;
+        do {
+            __builtin_amdgcn_s_sleep(4);
+            v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((++spins & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > poll_ticks) break;
+        } while (v == SLOT_EMPTY);
     }
     s = __uint_as_float((unsigned)(v & 0xffffffffull));
     q = __uint_as_float((unsigned)(v >> 32));
     return v != SLOT_EMPTY;
 }
 
+// Work assignment.  A cluster's `cl` workgroups must all be running for any of them to finish, so membership must not
+// depend on which workgroups the dispatcher happens to have placed: every workgroup draws TICKETS from one counter
+// (ticket t -> span t / cl, member t % cl).  All tickets below a drawn one are held by workgroups that are running (or
+// done), so at most ONE cluster is ever incomplete and every other running workgroup sits in a complete cluster, finishes
+// and draws the next ticket -- progress needs only `cl` running workgroups of this launch, whatever else shares the
+// device (a second stream or process, CU masks) and in whatever order the hardware dispatches.  The counter lives behind
+// the slots and is preset to 0xFFFFFFFF by the same memset (first draw wraps to 0).  STATIC = the round-1 scheme
+// (member = blockIdx): kept only as a diagnostic (ecm_gn3d_cluster_mode(2)).
+struct Tickets {
+    unsigned* ctr;
+    unsigned total, stride;
+    bool dynamic;
+    __device__ __forceinline__ unsigned first() const {
+        return dynamic ? atomicAdd(ctr, 1u) + 1u : blockIdx.x;
+    }
+    __device__ __forceinline__ unsigned next(unsigned t) const {
+        return dynamic ? atomicAdd(ctr, 1u) + 1u : t + stride;
+    }
+};
+
+__device__ __forceinline__ void report_timeout(unsigned* status) {
+    __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct FusedGeom {
-    int cpg, wpc, cl, nclusters, nspans;
+    int cpg, wpc, cl, nspans, grid;
     long long v4_per_wg;
     bool ok;
 };
+
+// cl <= FUSED_MAX_CL_RUN: a cluster never needs more than a quarter of the device to be running at once, so two or
+// three cluster launches sharing the device (streams, processes) cannot hold each other's last members out for good.
+constexpr int FUSED_MAX_CL_RUN = 128;
 
 inline FusedGeom fused_geom(int B, int C, long long S, int maxv4, int resident) {
     FusedGeom g{};
@@ -325,11 +358,13 @@ inline FusedGeom fused_geom(int B, int C, long long S, int maxv4, int resident) 
     if (g.cpg > FUSED_MAX_CPG) return g;
     const long long nv4 = S / 4, cap = (long long)THREADS * maxv4;
     const long long wpc = (nv4 + cap - 1) / cap;
-    if (wpc * g.cpg > FUSED_MAX_CL || wpc * g.cpg > resident) return g;
+    if (wpc * g.cpg > FUSED_MAX_CL_RUN || wpc * g.cpg * 4 > resident) return g;
     g.wpc = (int)wpc;
     g.cl = g.wpc * g.cpg;
     g.nspans = B * GROUPS;
-    g.nclusters = resident / g.cl < g.nspans ? resident / g.cl : g.nspans;
+    const long long total = (long long)g.nspans * g.cl;
+    if (total >= 0x7fffffffLL) return g;
+    g.grid = (int)(total < resident ? total : resident);
     g.v4_per_wg = (nv4 + wpc - 1) / wpc;
     g.ok = true;
     return g;
@@ -344,26 +379,38 @@ inline int resident_workgroups(K kern) {
     return cus * per;
 }
 
-// scratch layout of the fused path: slots [nspans][cl] x 64 bit (preset to SLOT_EMPTY by the launcher)
+// scratch layout of the fused path: slots [nspans][cl] x 64 bit, then the ticket counter (all preset to 0xFF.. by the launcher)
+struct FusedCtl {
+    unsigned long long* slots;
+    unsigned* ticket;
+    unsigned* status;                 // host-mapped sticky error word
+    unsigned long long poll_ticks;    // 100 MHz ticks
+    int dynamic;                      // 1: tickets, 0: static ids (diagnostic)
+};
+
 template <bool RELU, bool SKIP>
 __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ skip,
                                                            float* __restrict__ y, float* __restrict__ mean_rstd,
-                                                           unsigned long long* slots, int C, long long S, int cpg,
-                                                           int wpc, int nclusters, int nspans, long long v4_per_wg,
-                                                           float eps) {
+                                                           FusedCtl ctl, int C, long long S, int cpg,
+                                                           int wpc, int nspans, long long v4_per_wg, float eps) {
     constexpr int MAXV4 = FWD_MAXV4;
     __shared__ float sm[2 * THREADS / 64];
     __shared__ double smd[2 * THREADS / 64];
+    __shared__ unsigned tick_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = cpg * wpc;
-    const int cluster = blockIdx.x / cl, wic = blockIdx.x - cluster * cl;
-    const int cig = wic / wpc, w = wic - cig * wpc;
     const long long nv4 = S >> 2;                       // < 2^31 (checked by the host): 32-bit indices within a channel
-    const int v0 = (int)((long long)w * v4_per_wg);
-    const int v1 = (int)(v0 + v4_per_wg < nv4 ? v0 + v4_per_wg : nv4);
     const unsigned toff = (unsigned)(wave * MAXV4 * 64 + lane) * 16u;     // wave-contiguous rows of 64 float4 (1 KB)
-    for (int span = cluster; span < nspans; span += nclusters) {
+    const Tickets tk{ctl.ticket, (unsigned)nspans * (unsigned)cl, gridDim.x, ctl.dynamic != 0};
+    if (tid == 0) tick_s = tk.first();
+    __syncthreads();
+    unsigned t = tick_s;
+    while (t < tk.total) {
+        const int span = (int)(t / (unsigned)cl), wic = (int)(t - (unsigned)span * (unsigned)cl);
+        const int cig = wic / wpc, w = wic - cig * wpc;
+        const int v0 = (int)((long long)w * v4_per_wg);
+        const int v1 = (int)(v0 + v4_per_wg < nv4 ? v0 + v4_per_wg : nv4);
         const int b = span / GROUPS, g = span - b * GROUPS;
         const int c = g * cpg + cig;
         const size_t base = ((size_t)b * C + c) * S;
@@ -377,12 +424,13 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
             q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
         }
         block_reduce2(s, q, sm);
-        unsigned long long* sp = slots + (size_t)span * cl;
-        if (tid == 0) slot_publish(sp + wic, s, q);
-        // fixed-order total of the cl (<= 256) partials, identical in every workgroup of the cluster
+        unsigned long long* sp = ctl.slots + (size_t)span * cl;
+        unsigned tnext = 0;
+        if (tid == 0) { slot_publish(sp + wic, s, q); tnext = tk.next(t); }    // the draw's latency hides under the collect
+        // fixed-order total of the cl (<= 128) partials, identical in every workgroup of the cluster
         double ds = 0.0, dq = 0.0;
         int got = 1;
-        if (tid < cl) { float ps, pq; got = slot_collect(sp + tid, ps, pq) ? 1 : 0; ds = (double)ps; dq = (double)pq; }
+        if (tid < cl) { float ps, pq; got = slot_collect(sp + tid, ps, pq, ctl.poll_ticks) ? 1 : 0; ds = (double)ps; dq = (double)pq; }
         const bool arrived = __syncthreads_and(got) != 0;
         ds = wave_sum_d(ds); dq = wave_sum_d(dq);
         if (lane == 0) { smd[wave * 2] = ds; smd[wave * 2 + 1] = dq; }
@@ -394,7 +442,10 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         double var = dq / n - dmean * dmean;
         if (var < 0.0) var = 0.0;
         float mean = (float)dmean, rstd = (float)(1.0 / sqrt(var + (double)eps));
-        if (!arrived) mean = rstd = __builtin_nanf("");
+        if (!arrived) {
+            mean = rstd = __builtin_nanf("");
+            if (tid == 0) report_timeout(ctl.status);
+        }
         if (wic == 0 && tid == 0) { mean_rstd[span * 2] = mean; mean_rstd[span * 2 + 1] = rstd; }
         float a, sh;
         gn_affine(mean, rstd, gamma[c], beta[c], a, sh);
@@ -409,31 +460,41 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
             if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             slice_st(yr, toff + j * 1024, o);
         }
-        __syncthreads();          // smd / sm are reused by the next span
+        if (tid == 0) tick_s = tnext;
+        __syncthreads();          // tick_s; smd / sm are reused by the next span
+        t = tick_s;
     }
 }
 
 // MASK: 0 = no ReLU, 1 = mask from the forward output y, 2 = mask recomputed as fma(x, a, sh) > 0 (forward without skip)
-template <int MASK, bool GSKIP>
+// GSKIP: 0 = none, 1 = write the masked gradient to gskip, 2 = ACCUMULATE it into gskip (gskip += g: the residual's
+// gradient joins a gradient that is already there, e.g. cost0's fan-out to dres1 and the three hourglass residuals,
+// cmfsm.py:685-693, so no separate add kernel runs).
+template <int MASK, int GSKIP>
 __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const float* __restrict__ x, const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ y, const float* __restrict__ gy,
                                                            float* __restrict__ gx, float* __restrict__ gskip,
-                                                           float* __restrict__ chan, unsigned long long* slots, int C,
-                                                           long long S, int cpg, int wpc, int nclusters, int nspans,
+                                                           float* __restrict__ chan, FusedCtl ctl, int C,
+                                                           long long S, int cpg, int wpc, int nspans,
                                                            long long v4_per_wg) {
     constexpr int MAXV4 = BWD_MAXV4;
     __shared__ float sm[2 * THREADS / 64];
     __shared__ double chs[2 * FUSED_MAX_CPG];
+    __shared__ unsigned tick_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = cpg * wpc;
-    const int cluster = blockIdx.x / cl, wic = blockIdx.x - cluster * cl;
-    const int cig = wic / wpc, w = wic - cig * wpc;
     const long long nv4 = S >> 2;                       // < 2^31 (checked by the host): 32-bit indices within a channel
-    const int v0 = (int)((long long)w * v4_per_wg);
-    const int v1 = (int)(v0 + v4_per_wg < nv4 ? v0 + v4_per_wg : nv4);
     const unsigned toff = (unsigned)(wave * MAXV4 * 64 + lane) * 16u;     // wave-contiguous rows of 64 float4 (1 KB)
-    for (int span = cluster; span < nspans; span += nclusters) {
+    const Tickets tk{ctl.ticket, (unsigned)nspans * (unsigned)cl, gridDim.x, ctl.dynamic != 0};
+    if (tid == 0) tick_s = tk.first();
+    __syncthreads();
+    unsigned t = tick_s;
+    while (t < tk.total) {
+        const int span = (int)(t / (unsigned)cl), wic = (int)(t - (unsigned)span * (unsigned)cl);
+        const int cig = wic / wpc, w = wic - cig * wpc;
+        const int v0 = (int)((long long)w * v4_per_wg);
+        const int v1 = (int)(v0 + v4_per_wg < nv4 ? v0 + v4_per_wg : nv4);
         const int b = span / GROUPS, g = span - b * GROUPS;
         const int c = g * cpg + cig;
         const size_t base = ((size_t)b * C + c) * S;
@@ -463,7 +524,12 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
                 if (!(__builtin_fmaf(xx.z, a, sh) > 0.f)) gg.z = 0.f;
                 if (!(__builtin_fmaf(xx.w, a, sh) > 0.f)) gg.w = 0.f;
             }
-            if (GSKIP) slice_st(kr, toff + j * 1024, gg);
+            if (GSKIP == 1) slice_st(kr, toff + j * 1024, gg);
+            if (GSKIP == 2) {
+                float4 k = slice_ld(kr, toff + j * 1024);
+                k.x += gg.x; k.y += gg.y; k.z += gg.z; k.w += gg.w;
+                slice_st(kr, toff + j * 1024, k);
+            }
             // keep xhat (x itself is not needed again).  Past the slice x reads 0 => xhat = -mean*rstd, but g = 0 there.
             xx.x = (xx.x - mean) * rstd; xx.y = (xx.y - mean) * rstd;
             xx.z = (xx.z - mean) * rstd; xx.w = (xx.w - mean) * rstd;
@@ -472,21 +538,23 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
             xv[j] = xx; gv[j] = gg;
         }
         block_reduce2(sg, sgx, sm);
-        unsigned long long* sp = slots + (size_t)span * cl;
-        if (tid == 0) slot_publish(sp + wic, sg, sgx);
+        unsigned long long* sp = ctl.slots + (size_t)span * cl;
+        unsigned tnext = 0;
+        if (tid == 0) { slot_publish(sp + wic, sg, sgx); tnext = tk.next(t); }
         // per-channel totals (fixed order): wave k reduces the wpc partials of channels k, k+4, ...
         int got = 1;
         for (int cc = wave; cc < cpg; cc += THREADS / 64) {
             double ds = 0.0, dq = 0.0;
             for (int i = lane; i < wpc; i += 64) {
                 float ps, pq;
-                if (!slot_collect(sp + cc * wpc + i, ps, pq)) got = 0;
+                if (!slot_collect(sp + cc * wpc + i, ps, pq, ctl.poll_ticks)) got = 0;
                 ds += (double)ps; dq += (double)pq;
             }
             ds = wave_sum_d(ds); dq = wave_sum_d(dq);
             if (lane == 0) { chs[cc * 2] = ds; chs[cc * 2 + 1] = dq; }
         }
         const bool arrived = __syncthreads_and(got) != 0;
+        if (!arrived && tid == 0) report_timeout(ctl.status);
         float s1 = 0.f, s2 = 0.f;
         for (int j = 0; j < cpg; ++j) {
             const float gj = gamma[g * cpg + j];
@@ -509,11 +577,14 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
             o.w = rstd * (gv[j].w * gm - k1 - xv[j].w * k2);
             slice_st(orr, toff + j * 1024, o);
         }
-        __syncthreads();          // chs / sm are reused by the next span
+        if (tid == 0) tick_s = tnext;
+        __syncthreads();          // tick_s; chs / sm are reused by the next span
+        t = tick_s;
     }
 }
 
-inline long long fused_scratch_floats(int B) { return (long long)B * GROUPS * FUSED_MAX_CL * 2; }   // 64-bit slots
+// 64-bit slots [B*32][cl <= FUSED_MAX_CL_RUN] + one 16-byte line for the ticket counter, in floats
+inline long long fused_scratch_floats(int B) { return (long long)B * GROUPS * FUSED_MAX_CL_RUN * 2 + 4; }
 
 inline int chunks_of(long long n) { return (int)((n + CHUNK - 1) / CHUNK); }
 
@@ -561,41 +632,134 @@ extern "C" int ecm_gn3d_apply(const float* x, const float* mean_rstd, const floa
 
 namespace {
 
-// Launch helpers of the fused kernels; -100 = the shape needs the two-stage path.
+// ---- process-wide control of the cluster kernels ---------------------------------------------------------------------
+// mode: 1 = cluster kernels with ticket assignment (default), 0 = two-stage kernels only (no inter-workgroup waits at
+// all), 2 = cluster kernels with static member ids and 3 = a deliberately undersized grid (both diagnostics: 3 makes
+// every cluster time out so the error path can be tested).  Env ECM_GN_CLUSTER_MODE / ECM_GN_POLL_MS preset them.
+struct GnControl {
+    std::mutex mu;
+    int mode = 1;
+    unsigned long long poll_ticks = 200000000ull;      // 2 s at 100 MHz
+    unsigned* status_host = nullptr;                    // pinned, mapped: the kernels OR a bit in on a timeout
+    unsigned* status_dev = nullptr;
+    bool env_read = false;
+};
+GnControl& gn_ctl() { static GnControl c; return c; }
+
+int gn_ctl_init_locked(GnControl& c) {
+    if (!c.env_read) {
+        c.env_read = true;
+        if (const char* m = getenv("ECM_GN_CLUSTER_MODE")) c.mode = atoi(m);
+        if (const char* p = getenv("ECM_GN_POLL_MS")) { const long long ms = atoll(p); if (ms > 0) c.poll_ticks = (unsigned long long)ms * 100000ull; }
+    }
+    if (!c.status_host) {
+        void* h = nullptr;
+        hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable);
+        if (e != hipSuccess) return (int)e;
+        *static_cast<volatile unsigned*>(h) = 0u;
+        void* d = nullptr;
+        e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) { (void)hipHostFree(h); return (int)e; }
+        c.status_host = static_cast<unsigned*>(h);
+        c.status_dev = static_cast<unsigned*>(d);
+    }
+    return 0;
+}
+
+// Launch helpers of the fused kernels; -100 = the shape (or the mode) needs the two-stage path.
+struct FusedLaunch { FusedGeom g; FusedCtl ctl; int rc; };
+
+inline FusedLaunch fused_prepare(float* scratch, int B, int C, long long S, int maxv4, int resident, hipStream_t st) {
+    FusedLaunch L{};
+    GnControl& c = gn_ctl();
+    int mode;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        L.rc = gn_ctl_init_locked(c);
+        if (L.rc) return L;
+        mode = c.mode;
+        L.ctl.status = c.status_dev;
+        L.ctl.poll_ticks = c.poll_ticks;
+    }
+    L.rc = -100;
+    if (mode == 0) return L;
+    L.g = fused_geom(B, C, S, maxv4, resident);
+    if (!L.g.ok) return L;
+    if (mode == 2) L.g.grid -= L.g.grid % L.g.cl;                    // static ids: whole clusters only
+    if (mode == 3) L.g.grid = L.g.cl > 1 ? L.g.cl - 1 : 1;           // fault injection: a cluster can never be complete
+    if (mode == 3 && L.g.cl == 1) return L;
+    L.ctl.dynamic = mode == 2 ? 0 : 1;
+    L.ctl.slots = reinterpret_cast<unsigned long long*>(scratch);
+    const size_t nslots = (size_t)L.g.nspans * L.g.cl;
+    L.ctl.ticket = reinterpret_cast<unsigned*>(L.ctl.slots + nslots);
+    // one memset presets the slots to EMPTY and the ticket counter to 0xFFFFFFFF (first draw wraps to ticket 0)
+    const hipError_t e = hipMemsetAsync(L.ctl.slots, 0xff, nslots * sizeof(unsigned long long) + 16, st);
+    L.rc = e == hipSuccess ? 0 : (int)e;
+    return L;
+}
+
 template <bool RELU, bool SKIP>
 int launch_fused_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, float* mean_rstd,
                      float* scratch, int B, int C, long long S, float eps, hipStream_t st) {
     auto kern = gn_fused_fwd<RELU, SKIP>;
     static int resident = -1;
     if (resident < 0) resident = resident_workgroups(kern);
-    const FusedGeom g = fused_geom(B, C, S, FWD_MAXV4, resident);
-    if (!g.ok) return -100;
-    unsigned long long* slots = reinterpret_cast<unsigned long long*>(scratch);
-    hipError_t e = hipMemsetAsync(slots, 0xff, (size_t)g.nspans * g.cl * sizeof(unsigned long long), st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(g.nclusters * g.cl), dim3(THREADS), 0, st, x, gamma, beta, skip, y, mean_rstd, slots, C,
-                       S, g.cpg, g.wpc, g.nclusters, g.nspans, g.v4_per_wg, eps);
+    const FusedLaunch L = fused_prepare(scratch, B, C, S, FWD_MAXV4, resident, st);
+    if (L.rc) return L.rc;
+    hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), 0, st, x, gamma, beta, skip, y, mean_rstd, L.ctl, C,
+                       S, L.g.cpg, L.g.wpc, L.g.nspans, L.g.v4_per_wg, eps);
     return ECM_LAUNCH_RESULT();
 }
 
-template <int MASK, bool GSKIP>
+template <int MASK, int GSKIP>
 int launch_fused_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
                      const float* gy, float* gx, float* gskip, float* chan, float* scratch, int B, int C, long long S,
                      hipStream_t st) {
     auto kern = gn_fused_bwd<MASK, GSKIP>;
     static int resident = -1;
     if (resident < 0) resident = resident_workgroups(kern);
-    const FusedGeom g = fused_geom(B, C, S, BWD_MAXV4, resident);
-    if (!g.ok) return -100;
-    unsigned long long* slots = reinterpret_cast<unsigned long long*>(scratch);
-    hipError_t e = hipMemsetAsync(slots, 0xff, (size_t)g.nspans * g.cl * sizeof(unsigned long long), st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(g.nclusters * g.cl), dim3(THREADS), 0, st, x, mean_rstd, gamma, beta, y, gy, gx, gskip,
-                       chan, slots, C, S, g.cpg, g.wpc, g.nclusters, g.nspans, g.v4_per_wg);
+    const FusedLaunch L = fused_prepare(scratch, B, C, S, BWD_MAXV4, resident, st);
+    if (L.rc) return L.rc;
+    hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), 0, st, x, mean_rstd, gamma, beta, y, gy, gx, gskip,
+                       chan, L.ctl, C, S, L.g.cpg, L.g.wpc, L.g.nspans, L.g.v4_per_wg);
     return ECM_LAUNCH_RESULT();
 }
 
+// A cluster launch that timed out earlier leaves the sticky word set: every later GroupNorm call fails until cleared.
+inline int gn_pending_error() {
+    GnControl& c = gn_ctl();
+    std::lock_guard<std::mutex> lock(c.mu);
+    return (c.status_host && *static_cast<volatile unsigned*>(c.status_host)) ? ECM_EASYNC : 0;
+}
+
 }  // namespace
+
+extern "C" int ecm_gn3d_cluster_mode(int mode) {
+    GnControl& c = gn_ctl();
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.env_read = true;                       // an explicit call overrides the environment preset
+    const int old = c.mode;
+    if (mode >= 0 && mode <= 3) c.mode = mode;
+    return old;
+}
+
+extern "C" int ecm_gn3d_poll_ms(int ms) {
+    GnControl& c = gn_ctl();
+    std::lock_guard<std::mutex> lock(c.mu);
+    const int old = (int)(c.poll_ticks / 100000ull);
+    if (ms > 0) c.poll_ticks = (unsigned long long)ms * 100000ull;
+    return old;
+}
+
+extern "C" int ecm_async_status(int clear) {
+    GnControl& c = gn_ctl();
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (!c.status_host) return 0;
+    volatile unsigned* w = static_cast<volatile unsigned*>(c.status_host);
+    const unsigned v = *w;
+    if (clear) *w = 0u;
+    return v ? ECM_EASYNC : 0;
+}
 
 extern "C" int ecm_gn3d_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y,
                             float* mean_rstd, void* scratch, long long scratch_bytes, int B, int C, long long S,
@@ -603,6 +767,7 @@ extern "C" int ecm_gn3d_fwd(const float* x, const float* gamma, const float* bet
     ECM_CHECK_ARG(x && gamma && beta && y && mean_rstd && scratch && B > 0 && C > 0 && S > 0);
     if (C % GROUPS != 0 || (long long)B * C > 65535) return ECM_EUNSUP;
     if (scratch_bytes < ecm_gn3d_scratch_bytes(B, C, S)) return ECM_ESCRATCH;
+    if (const int pe = gn_pending_error()) return pe;
     hipStream_t st = ecm_stream(stream);
     float* sc = static_cast<float*>(scratch);
     int rc;
@@ -623,18 +788,19 @@ extern "C" int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float*
     ECM_CHECK_ARG(!relu || y || beta);          // the ReLU mask comes from y, or is recomputed from x with beta
     if (C % GROUPS != 0 || (long long)B * C > 65535) return ECM_EUNSUP;
     if (scratch_bytes < ecm_gn3d_scratch_bytes(B, C, S)) return ECM_ESCRATCH;
+    if (const int pe = gn_pending_error()) return pe;
     const int mask = !relu ? 0 : (y ? 1 : 2);
     hipStream_t st = ecm_stream(stream);
     float* sc = static_cast<float*>(scratch);
     {   // fused: chan lives behind the cluster slots
         float* chan = sc + fused_scratch_floats(B);
         int rc;
-        if (mask == 0) rc = gskip ? launch_fused_bwd<0, true>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
-                                  : launch_fused_bwd<0, false>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
-        else if (mask == 1) rc = gskip ? launch_fused_bwd<1, true>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
-                                       : launch_fused_bwd<1, false>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
-        else rc = gskip ? launch_fused_bwd<2, true>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
-                        : launch_fused_bwd<2, false>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
+        if (mask == 0) rc = gskip ? launch_fused_bwd<0, 1>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
+                                  : launch_fused_bwd<0, 0>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
+        else if (mask == 1) rc = gskip ? launch_fused_bwd<1, 1>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
+                                       : launch_fused_bwd<1, 0>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
+        else rc = gskip ? launch_fused_bwd<2, 1>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
+                        : launch_fused_bwd<2, 0>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
         if (rc == 0) {
             hipLaunchKernelGGL(gn_bwd_params, dim3((C + 63) / 64), dim3(64), 0, st, chan, ggamma, gbeta, B, C);
             return ECM_LAUNCH_RESULT();

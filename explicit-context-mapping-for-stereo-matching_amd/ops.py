@@ -693,3 +693,19 @@ def stereo_loss3(preds, gt, maxdisp=192, weights=(0.5, 0.7, 1.0)):
 
 def group_norm_act(x, gamma, beta, skip=None, relu=False):
     return GroupNormAct.apply(x, gamma, beta, skip, bool(relu))
+
+
+def gn_cluster_mode(mode=-1):
+    """Process-wide switch of the one-pass GroupNorm kernels (include/ecm_hip.h: ecm_gn3d_cluster_mode): 1 = cluster kernels
+    (default), 0 = two-stage kernels only -- the choice when several processes share one device; returns the previous mode."""
+    return _lib.query("ecm_gn3d_cluster_mode", int(mode))
+
+
+def check_async_errors(clear=True):
+    """Synchronise the current device and raise if a cluster kernel's bounded wait expired since the last check (its
+    outputs are NaN).  Call once per step (bench.py and the tests do); every later GroupNorm call raises on its own too."""
+    torch.cuda.synchronize()
+    rc = _lib.query("ecm_async_status", 1 if clear else 0)
+    if rc != 0:
+        msg = _lib.load().ecm_error_string(rc)
+        raise RuntimeError(f"asynchronous device-side failure ({rc}): {msg.decode() if msg else '?'}")

@@ -10,7 +10,8 @@
  *     enqueued asynchronously on it;
  *   - return 0 on success, a negative ECM_E* code on a bad argument, or the positive
  *     hipError_t of a failed launch; no exceptions cross the ABI;
- *   - re-entrant, no global mutable state.
+ *   - re-entrant; the only process-wide state is the sticky asynchronous-error word (ecm_async_status) and the
+ *     GroupNorm cluster mode (ecm_gn3d_cluster_mode), both documented below.
  *
  * Each function cites the reference interface (file:line under the reference repo)
  * it replaces; INTEGRATION.md shows the ctypes binding a maintainer would add.
@@ -25,6 +26,7 @@ extern "C" {
 #define ECM_EINVAL   (-1)   /* bad shape / null pointer */
 #define ECM_EUNSUP   (-2)   /* shape outside what the kernels are built for */
 #define ECM_ESCRATCH (-3)   /* caller-provided scratch too small */
+#define ECM_EASYNC   (-4)   /* an EARLIER asynchronous launch failed on the device (sticky; see ecm_async_status) */
 
 /* Library / build info. */
 int         ecm_abi_version(void);            /* bumps on any signature change */
@@ -174,6 +176,21 @@ int ecm_gn3d_stats(const float* x, float* mean_rstd, void* scratch, long long sc
                    int B, int C, long long S, float eps, void* stream);
 int ecm_gn3d_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
                    const float* skip, float* y, int B, int C, long long S, int relu, void* stream);
+/* The one-pass forms of ecm_gn3d_fwd / ecm_gn3d_bwd make workgroups of one launch wait for each other (a cluster of
+ * <= 128 workgroups per (sample, group) span exchanges partial sums).  Members are assigned by tickets drawn at run
+ * time, so progress needs only one cluster's worth of this launch's workgroups running, whatever else shares the
+ * device; every wait is bounded in wall time.  If a bound expires (device shared so heavily that a cluster never became
+ * resident within the poll time), the affected outputs are NaN AND a sticky, process-wide error word is set from the
+ * device: every later ecm_gn3d_* call returns ECM_EASYNC, and ecm_async_status(clear) reports (and optionally clears) it
+ * -- call it after synchronising the stream at the end of a step.  Never a hang, never a silent success.
+ *   ecm_gn3d_cluster_mode(mode): 1 = cluster kernels (default), 0 = two-stage kernels only (no inter-workgroup waits:
+ *     the safe choice when many processes share one device), 2 / 3 = diagnostics (static member ids / undersized grid that
+ *     forces the timeout path); any other value only queries.  Returns the previous mode.  Env ECM_GN_CLUSTER_MODE presets it.
+ *   ecm_gn3d_poll_ms(ms): wait bound in milliseconds (default 2000; ms <= 0 only queries).  Returns the previous bound. */
+int ecm_gn3d_cluster_mode(int mode);
+int ecm_gn3d_poll_ms(int ms);
+int ecm_async_status(int clear);
+
 /* Backward of y = relu?(gn(x) + skip): writes gx, gskip (NULL to skip it), ggamma[C] and gbeta[C].
  * ReLU mask (relu != 0): from the forward OUTPUT y when y != NULL; with y == NULL it is recomputed from x, which needs
  * beta and is only valid for a forward WITHOUT skip (saves one tensor read per pass).  beta may be NULL otherwise. */

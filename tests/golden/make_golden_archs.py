@@ -33,6 +33,11 @@ ARCHS = {  # name: (scale, h, w)
 }
 
 
+FULL_GRADS = ("dres0.0.0.weight", "dres0.2.1.weight", "dres2.conv6.0.weight", "dres2.conv5.1.bias", "classif1.2.weight",
+              "mapping_matrix.similarity1.conv0.weight", "mapping_matrix.similarity1.conv1.weight",
+              "mapping_matrix.similarity1.conv3.weight")
+
+
 class _Stub(torch.nn.Module):
     def __init__(self, feats):
         super().__init__()
@@ -77,6 +82,9 @@ for arch, (s, h, w) in ARCHS.items():
             out[nm] = t.grad
     for k, p in model.named_parameters():
         out["gn_" + k.replace(".", "_")] = p.grad.norm() if p.grad is not None else torch.zeros(())
+        # full-tensor gradients of a few parameters per architecture (a norm cannot see a permuted gradient)
+        if k in FULL_GRADS and p.grad is not None:
+            out["g_" + k.replace(".", "_")] = p.grad.clone()
     np.savez_compressed(os.path.join(OUT, f"arch_{arch}.npz"), **{k: v.detach().numpy() for k, v in out.items()})
     print(arch, [tuple(p.shape) for p in preds], "params", sum(v.numel() for v in sd.values()),
           f"{os.path.getsize(os.path.join(OUT, f'arch_{arch}.npz')) / 1024:.0f} KiB", flush=True)

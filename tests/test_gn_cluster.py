@@ -1,0 +1,93 @@
+"""Robustness of the one-pass GroupNorm cluster kernels (csrc/gn3d.hip; reference op: nn.GroupNorm of convbn_3d,
+cmfsm.py:58): workgroups of one launch wait for each other, so the tests cover what happens when the launch does NOT have
+the device to itself -- two streams issuing GroupNorm concurrently -- and what happens when a cluster can never complete
+(fault injection): a clean error (ECM_EASYNC -> RuntimeError), never a hang and never silent NaN with rc 0."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ecm():
+    assert torch.cuda.is_available()
+    import ecm_amd
+    return ecm_amd
+
+
+def _case(seed, shape):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(shape, device="cuda", generator=g) * 1.3 + 0.1
+    gm = torch.rand(shape[1], device="cuda", generator=g) + 0.5
+    bt = torch.randn(shape[1], device="cuda", generator=g) * 0.1
+    return x, gm, bt
+
+
+def test_groupnorm_two_streams_concurrently(ecm):
+    """GroupNorm forward + backward issued back to back on two streams of ONE device (each launch sized for the whole
+    device): every result must equal F.group_norm, and no cluster wait may expire."""
+    shape = (2, 32, 24, 144, 240)                      # clusters of 26 / 41 workgroups per span
+    cases = [_case(100 + i, shape) for i in range(2)]
+    refs = []
+    for x, gm, bt in cases:
+        xr = x.clone().requires_grad_()
+        r = F.relu(F.group_norm(xr, 32, gm, bt, 1e-5))
+        r.backward(torch.ones_like(r))
+        refs.append((r.detach(), xr.grad))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for rep in range(6):                               # interleave the issue order so the launches overlap on the device
+        for i in (0, 1):
+            x, gm, bt = cases[i]
+            with torch.cuda.stream(streams[i]):
+                xg = x.clone().requires_grad_()
+                y = ecm.ops.group_norm_act(xg, gm, bt, None, True)
+                y.backward(torch.ones_like(y))
+                outs[i].append((y.detach(), xg.grad))
+    ecm.ops.check_async_errors()                       # synchronises; raises if any bounded wait expired
+    for i in (0, 1):
+        for y, gx in outs[i]:
+            torch.testing.assert_close(y, refs[i][0], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(gx, refs[i][1], rtol=1e-3, atol=1e-4)
+
+
+def test_groupnorm_two_stage_mode_matches(ecm):
+    """ecm_gn3d_cluster_mode(0) routes to the two-stage kernels (no inter-workgroup waits): same values."""
+    x, gm, bt = _case(7, (1, 64, 8, 48, 96))
+    y1 = ecm.ops.group_norm_act(x, gm, bt, None, True)
+    old = ecm.ops.gn_cluster_mode(0)
+    try:
+        y0 = ecm.ops.group_norm_act(x, gm, bt, None, True)
+    finally:
+        ecm.ops.gn_cluster_mode(old)
+    torch.testing.assert_close(y0, y1, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(y1, F.relu(F.group_norm(x, 32, gm, bt, 1e-5)), rtol=1e-4, atol=1e-5)
+
+
+def test_cluster_timeout_is_a_clean_error(ecm):
+    """Fault injection (mode 3: the grid is one workgroup short of a cluster, so no cluster can ever complete): the launch
+    returns, its outputs are NaN, the sticky error word is set, the NEXT GroupNorm call raises, check_async_errors raises
+    and clears, and the path works again afterwards."""
+    lib = ecm._lib
+    x, gm, bt = _case(9, (1, 32, 8, 48, 96))           # 9216 float4 per channel -> 2 workgroups per cluster
+    old_mode = ecm.ops.gn_cluster_mode(3)
+    old_poll = lib.query("ecm_gn3d_poll_ms", 50)
+    try:
+        y = ecm.ops.group_norm_act(x, gm, bt, None, False)
+        torch.cuda.synchronize()
+        assert torch.isnan(y).any(), "a cluster that never completed must poison its outputs"
+        assert lib.query("ecm_async_status", 0) == -4
+        with pytest.raises(RuntimeError, match="timed out"):
+            ecm.ops.group_norm_act(x, gm, bt, None, False)
+        with pytest.raises(RuntimeError, match="timed out"):
+            ecm.ops.check_async_errors()
+        assert lib.query("ecm_async_status", 0) == 0   # cleared by the check
+    finally:
+        lib.query("ecm_async_status", 1)
+        ecm.ops.gn_cluster_mode(old_mode)
+        lib.query("ecm_gn3d_poll_ms", old_poll)
+    y = ecm.ops.group_norm_act(x, gm, bt, None, False)
+    torch.testing.assert_close(y, F.group_norm(x, 32, gm, bt, 1e-5), rtol=1e-4, atol=1e-5)
+    ecm.ops.check_async_errors()

@@ -368,6 +368,9 @@ def test_full_model_train_step_golden(ecm, cmfsm_sd):
         ref = float(g["gn_" + k.replace(".", "_")])
         got = float(params[k].grad.norm())
         assert abs(got - ref) <= 2e-2 * ref + 1e-7, (k, got, ref)
+        ref_t = g["g_" + k.replace(".", "_")]                    # full tensor, whole-tensor bound
+        err = float((params[k].grad.cpu() - ref_t).abs().max())
+        assert err <= 2e-2 * float(ref_t.abs().max()) + 1e-9, (k, err, float(ref_t.abs().max()))
 
 
 def test_hot_path_explicit_cost_volume_agrees(ecm, cmfsm_sd):
@@ -582,12 +585,20 @@ def test_arch_hot_path_golden(ecm, arch):
             ref = g[nm]
             tol = 2e-2 * float(ref.abs().max()) + 1e-6
             assert (t_.grad.cpu() - ref).abs().max() <= tol, (arch, nm, float((t_.grad.cpu() - ref).abs().max()), tol)
+    checked_full = 0
     for k, v in model.named_parameters():
         if k.startswith("feature_extraction"):
             continue
-        ref_norm = float(g["gn_" + k.replace(".", "_")])
+        kk = k.replace(".", "_")
+        ref_norm = float(g["gn_" + kk])
         got = float(v.grad.norm()) if v.grad is not None else 0.0
         assert abs(got - ref_norm) <= 2e-2 * ref_norm + 1e-5, (arch, k, got, ref_norm)
+        if "g_" + kk in g:          # full tensors for a few parameters per architecture: a norm cannot see a permutation
+            ref_t = g["g_" + kk]
+            err = float((v.grad.cpu() - ref_t).abs().max())
+            assert err <= 2e-2 * float(ref_t.abs().max()) + 1e-6, (arch, k, err, float(ref_t.abs().max()))
+            checked_full += 1
+    assert checked_full >= 4, (arch, checked_full)
 
 
 def test_arch_state_dict_contracts(ecm):

@@ -7,8 +7,11 @@ ms per cost volume, on N MI355X of one node.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant kernel, live HIP-event timing),
-`roofline_costvol` (the HBM-bound cost-volume build), `cpu_baseline` (the oracle port on host cores; N=1 only).
+Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant kernel, live HIP-event timing), `roofline_costvol`
+(the HBM-bound cost-volume build), `roofline_worst` (the kernels furthest below their roofline, live-timed in the same
+steps), `configs` (N=1 only: the other BASELINE.json configurations that fit one GPU -- eval forward of cfg 1, the KITTI
+frame and the 256x512 training crop of cfg 4, the cfg 5 cost-volume microbench -- each with its own steps / ms so the
+driver's clock can bound them), `cpu_baseline` (the oracle port on host cores; N=1 only).
 Synthetic data (N(0,1) images, U(0,191) ground truth), random-init weights (reference init rule).
 """
 from __future__ import annotations
@@ -39,6 +42,7 @@ def parse():
     ap.add_argument("--maxdisp", type=int, default=192)
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `configs` and explicit-cost-volume readings (N=1)")
     ap.add_argument("--graph", action="store_true", help="--mode infer only: replay the forward as one captured HIP graph")
     ap.add_argument("--explicit-cost-volume", action="store_true",
                    help="run the reference's explicit op sequence (4-D concat volume + 64->32 Conv3d) instead of the collapsed 2-D form")
@@ -46,29 +50,76 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(threads: int, H: int, W: int):
-    """Oracle (CPU port of the reference op sequence) on a bounded sample of the same workload: ONE pair at the
-    bench resolution, forward + backward of the training loss (about 20 s on 16 host threads)."""
+    """The oracle (CPU port of the reference op sequence) on a bounded sample of the bench workload, on this box's host
+    cores: ONE pair at the bench resolution --
+      * fwd + bwd of the training loss, one sample (the headline metric's workload; `value`);
+      * eval forward under no_grad: one warm-up + three timed runs on N = all available cores (capped at 16, a 1-GPU box's
+        share) and one timed run on 8 threads (comparable with SURVEY section 6's 26.8 s of the reference on 8 cores);
+      * the cost-volume stage alone (python loop over disparities, cmfsm.py:667-682)."""
     from oracle import ecm_oracle as O
     import ecm_amd
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = threads or min(avail, 16)            # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
+    cores = threads or min(avail, 16)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(1234)
     model = ecm_amd.get_model("cmfsm")           # CPU instance used only as a weight container (reference init rule)
-    sd = {k: v.detach().clone().requires_grad_() for k, v in model.state_dict().items()}
+    sd_plain = {k: v.detach().clone() for k, v in model.state_dict().items()}
     left, right = torch.randn(1, 3, H, W, generator=g), torch.randn(1, 3, H, W, generator=g)
     gt = torch.rand(1, H, W, generator=g) * 191.0
+    fwd = []
+    with torch.no_grad():
+        O.cmfsm_forward(left, right, sd_plain)                     # warm-up
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.cmfsm_forward(left, right, sd_plain)
+            fwd.append(time.perf_counter() - t0)
+        fl, fr = torch.randn(1, 32, H // 4, W // 4, generator=g), torch.randn(1, 32, H // 4, W // 4, generator=g)
+        t0 = time.perf_counter()
+        O.cost_volume(fl, fr, 48)
+        cv_s = time.perf_counter() - t0
+        n8 = None
+        if cores > 8:
+            torch.set_num_threads(8)
+            t0 = time.perf_counter()
+            O.cmfsm_forward(left, right, sd_plain)
+            n8 = time.perf_counter() - t0
+            torch.set_num_threads(cores)
+    sd = {k: v.detach().clone().requires_grad_() for k, v in sd_plain.items()}
     t0 = time.perf_counter()
-    preds = O.cmfsm_forward(left, right, sd)
-    t1 = time.perf_counter()
-    loss = O.train_loss(preds, gt)
+    loss = O.train_loss(O.cmfsm_forward(left, right, sd), gt)
     loss.backward()
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 pair {W}x{H} D=192, fwd+bwd of the training loss, {dt:.1f} s (fwd {t1 - t0:.1f} s); "
-                      f"torch CPU fp32, {cores} threads",
-            "seconds": dt, "fwd_only_pairs_per_s": 1.0 / (t1 - t0)}
+    fmean = sum(fwd) / len(fwd)
+    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "sample": f"1 pair {W}x{H} D=192: fwd+bwd of the training loss once ({dt:.1f} s) = `value`; eval forward 1 warm-up + 3 "
+                      f"timed ({fmean:.2f} s mean); torch CPU fp32, {cores} threads",
+            "seconds": dt,
+            "eval_forward": {"pairs_per_s": 1.0 / fmean, "seconds": fwd, "threads": cores,
+                             "threads8_seconds": n8, "threads8_pairs_per_s": (1.0 / n8) if n8 else None},
+            "cost_volume_ms": cv_s * 1e3}
+
+
+def _timed(fn, steps, warmup, sync):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / steps
 
 
 def main():
@@ -76,7 +127,8 @@ def main():
     import ecm_amd
     from importlib import import_module
     ecm_dist = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
-    lib = ecm_amd._lib
+    mdl = import_module("explicit-context-mapping-for-stereo-matching_amd.models")
+    lib, ops = ecm_amd._lib, ecm_amd.ops
 
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the HIP path has no CPU fallback)"
     # one process per GPU over RCCL ("nccl"); ECM_DIST_BACKEND=gloo lets several ranks rehearse the N>1 path on a
@@ -87,33 +139,44 @@ def main():
     torch.cuda.set_device(local)
     rank, world, _ = ecm_dist.init_from_env(backend, device=local)
     assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world > ndev:
+        # several PROCESSES on one device: the one-pass GroupNorm kernels wait across workgroups, which is only safe to
+        # rely on when at most a few launches share the device -- take the two-stage kernels (no inter-workgroup waits)
+        ops.gn_cluster_mode(0)
     dev = torch.device("cuda", local)
     # The reference sets cudnn.benchmark=True (train.py:26); on ROCm that means an exhaustive MIOpen search per conv
-    # shape (minutes at this size), so the encoder runs on MIOpen's immediate-mode picks instead.
+    # shape (minutes at this size), so what is left of the encoder on MIOpen runs on its immediate-mode picks instead.
     torch.backends.cudnn.benchmark = False
 
     if args.explicit_cost_volume:
-        import_module("explicit-context-mapping-for-stereo-matching_amd.models").EXPLICIT_COST_VOLUME = True
+        mdl.EXPLICIT_COST_VOLUME = True
     torch.manual_seed(0)
     model = ecm_amd.get_model("cmfsm").to(dev)
     B, H, W, D = args.batch, args.height, args.width, args.maxdisp
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    left = torch.randn(B, 3, H, W, generator=g).to(dev)
-    right = torch.randn(B, 3, H, W, generator=g).to(dev)
-    gt = (torch.rand(B, H, W, generator=g) * 191.0).to(dev)
 
+    def make_inputs(b, h, w, seed):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        return (torch.randn(b, 3, h, w, generator=g).to(dev), torch.randn(b, 3, h, w, generator=g).to(dev),
+                (torch.rand(b, h, w, generator=g) * 191.0).to(dev))
+
+    left, right, gt = make_inputs(B, H, W, 1234 + rank)
+    ddp = opt = None
     if args.mode == "train":
         model.train()
         ddp = ecm_dist.FlatBucketDDP(model, world)
         opt = torch.optim.Adam(ddp.params, lr=1e-3, betas=(0.9, 0.999), fused=True)   # train.py:85-86 (fused: same update rule)
 
+    def train_step(l, r, g):
+        ddp.zero_grad()
+        loss, count = ecm_dist.masked_smooth_l1_x3_with_count(model(l, r), g, D)      # train.py:162-174
+        ddp.global_mean_loss(loss, count).backward()                                  # one masked mean over the GLOBAL batch
+        ddp.allreduce_gradients()
+        opt.step()
+        return loss
+
+    if args.mode == "train":
         def step():
-            ddp.zero_grad()
-            loss = ecm_dist.masked_smooth_l1_x3(model(left, right), gt, D)
-            loss.backward()
-            ddp.allreduce_gradients()
-            opt.step()
-            return loss
+            return train_step(left, right, gt)
     else:
         model.eval()
         if args.graph:
@@ -140,8 +203,11 @@ def main():
         step()
         torch.cuda.synchronize()
         note(f"warmup step {i + 1}/{args.warmup} done")
-    # time EXACTLY K steps; the dominant kernels are also event-timed per launch on the launch stream
-    lib.enable_timer("ecm_conv3d_k3_fwd")
+    # time EXACTLY K steps; the dominant kernels and the worst-roofline kernels are also event-timed per launch on the
+    # launch stream
+    TIMED = ("ecm_conv3d_k3_fwd", "ecm_conv3d_k3_wgrad", "ecm_conv3d_c1_fwd", "ecm_weights9_fwd")
+    for name in TIMED:
+        lib.enable_timer(name)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -149,33 +215,84 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timers = lib.disable_timers()
+    ops.check_async_errors()                               # a GroupNorm cluster time-out during the timed steps is fatal
     last = step()                                          # outside the timed region: the result must be finite
     assert bool(torch.isfinite(last).all()), "non-finite loss / disparity after the timed steps"
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-
     note(f"timed {args.steps} steps in {dt:.3f} s")
+
+    extras = world == 1 and not args.no_extras and args.mode == "train" and not args.explicit_cost_volume
+    sync = torch.cuda.synchronize
     # second reading (1 GPU only): the same step with the reference's explicit op sequence -- 4-D concat volume built by
     # the cost-volume kernel + 64->32 Conv3d on it -- so both forms are on record in the same JSON line
     explicit = None
-    if world == 1 and not args.explicit_cost_volume and not args.graph:
-        mdl = import_module("explicit-context-mapping-for-stereo-matching_amd.models")
+    configs = {}
+    if extras:
         mdl.EXPLICIT_COST_VOLUME = True
         try:
-            step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            dte = time.perf_counter() - t1
-            explicit = {"ms_per_step": 1e3 * dte / args.steps, "value": B * args.steps / dte, "unit": "pairs/s",
+            ms = _timed(step, args.steps, 1, sync) * 1e3
+            explicit = {"ms_per_step": ms, "value": B / ms * 1e3, "unit": "pairs/s", "steps": args.steps,
                         "note": "same step with ops.cost_volume (explicit [B,2C,D',h,w] tensor) + 64->32 Conv3d"}
         finally:
             mdl.EXPLICIT_COST_VOLUME = False
         note(f"explicit-cost-volume variant: {explicit['ms_per_step']:.1f} ms/step")
+
+        # ---- the other BASELINE.json configurations that fit one GPU -------------------------------------------------
+        # cfg 4 (KITTI fine-tune, 1 pair per GPU): the reference trains on 256x512 crops (KITTI.py:84-97) and evaluates the
+        # padded 384x1248 frame; both shapes as a full training step, as SURVEY 8d asks
+        for key, (b, h, w, st, wu, label) in {
+            "cfg4_kitti_384x1248_train": (1, 384, 1248, 5, 2, "KITTI-2015 1242x375 padded to 1248x384, batch 1/GPU, fwd+bwd+Adam"),
+            "cfg4_crop_256x512_train": (4, 256, 512, 5, 2, "256x512 training crop (Flying3d.py:51-56 / KITTI.py:84-97), batch 4/GPU, fwd+bwd+Adam"),
+        }.items():
+            l2, r2, g2 = make_inputs(b, h, w, 77)
+            ms = _timed(lambda: train_step(l2, r2, g2), st, wu, sync) * 1e3
+            configs[key] = {"ms_per_step": ms, "value": b / ms * 1e3, "unit": "pairs/s", "steps": st, "warmup": wu, "workload": label}
+            note(f"{key}: {ms:.1f} ms/step")
+            del l2, r2, g2
+        # cfg 1: single 960x540 pair, eval forward as test.py runs it (no_grad, crop [:540,:960], EPE of output3)
+        model.eval()
+        l1, r1, g1 = make_inputs(1, H, W, 78)
+
+        def eval_step():
+            with torch.no_grad():
+                return ops.eval_epe(model(l1, r1)[2], g1, min(540, H), min(960, W), D)
+        ms = _timed(eval_step, 10, 3, sync) * 1e3
+        configs["cfg1_eval_forward_b1"] = {"ms_per_step": ms, "value": 1e3 / ms, "unit": "pairs/s", "steps": 10, "warmup": 3,
+                                           "workload": "single 960x540 pair (padded to 576), eval forward + crop + EPE (test.py:63-94)"}
+        lb, rb, _ = make_inputs(B, H, W, 79)
+
+        def eval_step_b():
+            with torch.no_grad():
+                return model(lb, rb)[2]
+        ms = _timed(eval_step_b, 5, 2, sync) * 1e3
+        configs["cfg1_eval_forward_b4"] = {"ms_per_step": ms, "value": B / ms * 1e3, "unit": "pairs/s", "steps": 5, "warmup": 2,
+                                           "workload": f"eval forward, batch {B}"}
+        note(f"eval forward: {configs['cfg1_eval_forward_b1']['ms_per_step']:.2f} ms/pair at B=1, "
+             f"{configs['cfg1_eval_forward_b4']['value']:.1f} pairs/s at B={B}")
+        model.train()
+        del l1, r1, g1, lb, rb
+        # cfg 5: cost-volume microbench, 1920x1080 D=256 -> L,R [1,32,270,480], D'=64, 2.16 GB per build
+        f5l, f5r = (torch.randn(1, 32, 270, 480, device=dev) for _ in range(2))
+        for _ in range(5):
+            ops.cost_volume(f5l, f5r, 64)
+        sync()
+        lib.enable_timer("ecm_costvol_concat_fwd")
+        for _ in range(20):
+            ops.cost_volume(f5l, f5r, 64)
+        sync()
+        ev = lib.disable_timers()["ecm_costvol_concat_fwd"]
+        ms5 = sum(s.elapsed_time(e) for s, e, _ in ev) / len(ev)
+        bytes5 = (2 * 32 * 64 * 270 * 480 + 2 * 32 * 270 * 480) * 4.0
+        configs["cfg5_cost_volume_1080p_d256"] = {"ms_per_cost_volume": ms5, "steps": 20, "warmup": 5, "bytes": bytes5,
+                                                  "achieved_GBs": bytes5 / ms5 / 1e6, "frac_of_hbm_peak": bytes5 / ms5 / 1e6 / PEAK_HBM_GBS,
+                                                  "workload": "L,R [1,32,270,480], D'=64 -> [1,64,64,270,480] (2.16 GB)"}
+        note(f"cfg5 cost volume: {ms5:.3f} ms")
+        del f5l, f5r
+        ops.check_async_errors()
+
     if rank == 0:
         h, w, Dl = H // 4, W // 4, D // 4
         # "ms per cost-volume build" (BASELINE.json's second metric) is the stand-alone build of the reference's full
@@ -183,45 +300,83 @@ def main():
         # inside the model the volume is never materialised: its convolution collapses to 2-D ones (ops.costvol_conv3d).
         fl, fr = (torch.randn(B, 32, h, w, device=dev) for _ in range(2))
         for _ in range(3):
-            ecm_amd.ops.cost_volume(fl, fr, Dl)
+            ops.cost_volume(fl, fr, Dl)
         torch.cuda.synchronize()
         lib.enable_timer("ecm_costvol_concat_fwd")
         for _ in range(10):
-            ecm_amd.ops.cost_volume(fl, fr, Dl)
+            ops.cost_volume(fl, fr, Dl)
         torch.cuda.synchronize()
         timers.update(lib.disable_timers())
         del fl, fr
+
+        def ms_of(evs):
+            return sum(s.elapsed_time(e) for s, e in evs) / max(1, len(evs))
+
         # dominant kernel SYMBOL: conv3d_k3_mfma<1,1,4,8,4> = every ecm_conv3d_k3_fwd launch with stride 1 and Co <= 32
         # (forward convs, and in training the stride-1 data gradients that run on the same kernel).
         # int args of the call: (B, Ci, Co, D, H, W, stride).  achieved = sum(algorithmic FLOPs) / sum(duration).
-        sel = [(s, e, a) for (s, e, a) in timers["ecm_conv3d_k3_fwd"] if a[6] == 1 and a[2] <= 32]
+        sel = [(s, e, a) for (s, e, a) in timers.get("ecm_conv3d_k3_fwd", []) if a[6] == 1 and a[2] <= 32]
         conv_total_ms = sum(s.elapsed_time(e) for s, e, _ in sel)
         conv_ms = conv_total_ms / max(1, len(sel))
         conv_flop = sum(2.0 * 27 * a[1] * a[2] * a[3] * a[4] * a[5] * a[0] for _, _, a in sel)
         conv_tf = conv_flop / (conv_total_ms * 1e-3) / 1e12 if sel else 0.0
-        main = [(s, e) for (s, e, a) in sel if a[1] == 32 and a[2] == 32]
-        main_ms = sum(s.elapsed_time(e) for s, e in main) / max(1, len(main))
-        main_tf = 2.0 * 27 * 32 * 32 * Dl * h * w * B / (main_ms * 1e-3) / 1e12 if main else 0.0
+        main_l = [(s, e) for (s, e, a) in sel if a[1] == 32 and a[2] == 32]
+        main_ms = ms_of(main_l)
+        main_tf = 2.0 * 27 * 32 * 32 * Dl * h * w * B / (main_ms * 1e-3) / 1e12 if main_l else 0.0
         cv = [(s, e) for (s, e, a) in timers["ecm_costvol_concat_fwd"]]
-        cv_ms = sum(s.elapsed_time(e) for s, e in cv) / max(1, len(cv))
+        cv_ms = ms_of(cv)
         cv_bytes = (2 * 32 * Dl * h * w + 2 * 32 * h * w) * 4.0 * B
         cv_gbs = cv_bytes / (cv_ms * 1e-3) / 1e9 if cv else 0.0
         pairs = B * world * args.steps
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs,
-        # gfx950 corrections applied as profiles/r01_pmc_traffic.json says), measured at B=1 and scaled by B.
-        traffic_cv = traffic_conv = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pm = json.load(f)
-            if (H, W, D) == (576, 960, 192):
-                traffic_cv = pm["costvol_fwd_v4"]["hbm_bytes_per_launch_B1"] * B
-                cv_pm = pm["conv3d_k3_mfma<1,1,4,8,4> 32->32"]
-                traffic_conv = cv_pm["hbm_bytes_per_launch_B4_xcd_aware"] if B == 4 and "hbm_bytes_per_launch_B4_xcd_aware" in cv_pm \
-                    else cv_pm["hbm_bytes_per_launch_B1"] * B
-        except (OSError, KeyError, ValueError):
-            pass
+
+        # kernels furthest below their roofline, live-timed in the same steps
+        worst = {}
+        wg2 = [(s, e, a) for (s, e, a) in timers.get("ecm_conv3d_k3_wgrad", []) if a[6] == 2]     # (B,Ci,Co,D,H,W,stride)
+        if wg2:
+            tot = sum(s.elapsed_time(e) for s, e, _ in wg2)
+            flop = sum(2.0 * 27 * a[1] * a[2] * a[0] * ((a[3] - 1) // 2 + 1) * ((a[4] - 1) // 2 + 1) * ((a[5] - 1) // 2 + 1) for _, _, a in wg2)
+            tf = flop / (tot * 1e-3) / 1e12
+            worst["conv3d_wgrad_stride2"] = {"kernel": "conv3d_wgrad_mfma (stride-2 layers: hourglass conv1/conv3 and the deconvs' weight gradients)",
+                                             "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": tf / PEAK_F32_MFMA_TFLOPS, "launches_timed": len(wg2), "avg_launch_ms": tot / len(wg2)}
+        c1 = [(s, e, a) for (s, e, a) in timers.get("ecm_conv3d_c1_fwd", [])]                     # (B,Ci,D,H,W)
+        if c1:
+            tot = sum(s.elapsed_time(e) for s, e, _ in c1)
+            byt = sum((a[1] + 1) * 4.0 * a[0] * a[2] * a[3] * a[4] for _, _, a in c1)
+            gbs = byt / (tot * 1e-3) / 1e9
+            worst["conv3d_c1_fwd"] = {"kernel": "conv3d_c1_fwd (classifier 32->1)", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                                      "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "launches_timed": len(c1), "avg_launch_ms": tot / len(c1)}
+        ew = [(s, e, a) for (s, e, a) in timers.get("ecm_weights9_fwd", [])]                      # (B,h,w,s)
+        if ew:
+            tot = sum(s.elapsed_time(e) for s, e, _ in ew)
+            # bound = max(HBM time, fp32 time): 32*(H*W + h*w)*4 + 9*H*W*4 bytes; factorised MLP flops per SURVEY 8d
+            bound_ms = 0.0
+            for _, _, a in ew:
+                bb, hh, ww, ss = a[0], a[1], a[2], a[3]
+                HW = hh * ss * ww * ss
+                byt = bb * (32 * (HW + hh * ww) + 9 * HW) * 4.0
+                flop = bb * (2.0 * 32 * 32 * (HW + hh * ww) + 9 * HW * 2.0 * (32 * 16 + 16 * 8 + 8 + 2 * 32))
+                bound_ms += max(byt / (PEAK_HBM_GBS * 1e9), flop / (PEAK_F32_MFMA_TFLOPS * 1e12)) * 1e3
+            worst["ecm_weights9_fwd"] = {"kernel": "ecm_lr_proj + ecm_weights_fwd_kernel<0>", "bound": "max(hbm, fp32)",
+                                         "bound_ms_per_launch": bound_ms / len(ew), "avg_launch_ms": tot / len(ew),
+                                         "frac": bound_ms / tot, "launches_timed": len(ew)}
+
         shape_name = {(576, 960): "SceneFlow 960x540 (padded to 576)",
                       (384, 1248): "KITTI-2015 1242x375 (padded to 1248x384)"}.get((H, W), f"synthetic {W}x{H}")
+        # roofline.traffic: HBM bytes per launch from rocprofv3 PMC passes of THIS round (profiles/r02_pmc_traffic.json, written
+        # by tools/pmc_traffic.py with the calibration of tools/micro/fetch_calib.hip applied); null until that file exists --
+        # round 1's figure used an uncalibrated FETCH_SIZE for 4-byte-per-lane buffer loads and read below the algorithmic bytes.
+        traffic_cv = traffic_conv = None
+        traffic_note = "no calibrated PMC pass on file (profiles/r02_pmc_traffic.json)"
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            if (H, W, D, B) == (576, 960, 192, 4):
+                traffic_conv = pm["conv3d_k3_mfma_32to32_B4"]["hbm_bytes_per_launch"]
+                traffic_cv = pm["costvol_fwd_v4_B4"]["hbm_bytes_per_launch"]
+                traffic_note = pm.get("note", "rocprofv3 PMC, calibrated (profiles/r02_pmc_traffic.json)")
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "stereo-pairs/sec (cmfsm train step fwd+bwd+Adam)" if args.mode == "train"
                       else "stereo-pairs/sec (cmfsm eval forward)",
@@ -231,27 +386,28 @@ def main():
             "config": {"workload": f"{shape_name} D={D} batch={B}/GPU "
                                    f"{'fwd+bwd+Adam (train.py path)' if args.mode == 'train' else 'eval forward (test.py path)'}",
                        "arch": "cmfsm", "global_batch": B * world, "parallelism": f"dp{world}",
-                       "cost_volume": "explicit 4-D tensor" if args.explicit_cost_volume else "collapsed into 2-D convolutions",
+                       "cost_volume": "explicit 4-D tensor" if args.explicit_cost_volume else "collapsed into class-indexed 2-D convolutions",
                        "launch": "hip graph replay" if (args.mode == "infer" and args.graph) else "eager"},
             "ms_per_cost_volume": cv_ms / B,
             "roofline": {"kernel": "conv3d_k3_mfma<1,1,4,8,4> (all stride-1, Co<=32 launches: fwd + dgrad)", "bound": "mfma",
                          "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_conv,
-                         "traffic_note": "HBM bytes of one 32->32 launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
-                         "launches_timed": len(sel),
-                         "avg_launch_ms": conv_ms,
+                         "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_conv, "traffic_note": traffic_note,
+                         "launches_timed": len(sel), "avg_launch_ms": conv_ms,
                          "of_which_32to32": {"achieved": main_tf, "frac": main_tf / PEAK_F32_MFMA_TFLOPS,
-                                             "avg_launch_ms": main_ms, "launches_timed": len(main)}},
+                                             "avg_launch_ms": main_ms, "launches_timed": len(main_l)}},
             "roofline_costvol": {"kernel": "costvol_fwd_v4", "bound": "hbm", "achieved": cv_gbs, "peak": PEAK_HBM_GBS,
                                  "unit": "GB/s", "frac": cv_gbs / PEAK_HBM_GBS, "traffic": traffic_cv,
                                  "launches_timed": len(cv), "avg_launch_ms": cv_ms},
+            "roofline_worst": worst,
         }
         if explicit is not None:
             out["explicit_cost_volume"] = explicit
+        if configs:
+            out["configs"] = configs
         if world == 1 and not args.no_cpu_baseline:
-            note("cpu baseline (oracle port, 1 pair fwd+bwd at the bench resolution) ...")
+            note("cpu baseline (oracle port: 1 pair at the bench resolution; 4 eval forwards + 1 fwd+bwd) ...")
             cb = cpu_baseline(args.cpu_threads, H, W)
-            note(f"cpu baseline done: {cb['seconds']:.1f} s")
+            note(f"cpu baseline done: fwd+bwd {cb['seconds']:.1f} s, eval forward {1.0 / cb['eval_forward']['pairs_per_s']:.2f} s")
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -57,6 +57,11 @@ PROTOTYPES = {
     "ecm_costvol_conv_assemble_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ecm_costvol_conv_assemble_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ecm_frame_prep": (_I, [_P] * 5 + [_I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "ecm_frame_prep_kitti_eval": (_I, [_P] * 5 + [_I, _I, _I, _I, _I, _P, _P, _P]),
+    "ecm_frame_prep_packed": (_I, [_P, _P, _I] + [_P] * 4 + [_I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "ecm_eval_epe_scratch_bytes": (_LL, [_LL]),
+    "ecm_eval_epe": (_I, [_P, _P, _P, _P, _LL] + [_I] * 7 + [_F, _P]),
+    "ecm_disp_to_u16": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _I, _F, _P]),
     "ecm_gn3d_cluster_mode": (_I, [_I]),
     "ecm_gn3d_poll_ms": (_I, [_I]),
     "ecm_async_status": (_I, [_I]),

@@ -43,25 +43,55 @@ def shard_batch(n_items: int, rank: int, world: int):
 
 class FlatBucketDDP:
     """Owns one flat gradient buffer; after `allreduce_gradients()` every parameter's .grad is a view into it, so the whole
-    model's gradient is exchanged with a single all-reduce (5,255,368 floats = 21 MB for cmfsm).
+    model's gradient is exchanged with one all-reduce per bucket slice (5,255,368 floats = 21 MB for cmfsm).
 
     `zero_grad()` drops the gradients (None) instead of zeroing the bucket: autograd then hands each parameter its freshly
     computed gradient tensor instead of launching one `grad += new` kernel per parameter (≈280 tiny adds per step for
-    cmfsm), and `allreduce_gradients()` gathers them into the bucket with ONE multi-tensor copy."""
+    cmfsm), and the gradients are gathered into the bucket with ONE multi-tensor copy per slice.
 
-    def __init__(self, module: torch.nn.Module, world: int | None = None):
+    Overlap: backward finishes the hot path (3-D stack, ECM, heads) before it enters the 2-D encoder, so with
+    `late_module` = the encoder's attribute name the bucket is split into the encoder's slice and the rest; as soon as the
+    gradient has flowed back into ALL of the encoder's outputs (tensor hooks; their number is learnt on the first step) the
+    rest-slice is gathered and its all-reduce is started on a side stream, under the encoder's backward.  The encoder slice
+    follows at the end of backward.  world == 1 installs nothing.
+
+    Loss semantics: the reference's loss is ONE masked mean over the whole gathered batch (train.py:162-174 behind
+    nn.DataParallel's gather), which is not the average of per-rank masked means when the ranks' mask counts differ.
+    `global_mean_loss(loss, count)` rescales the rank's loss by count_r / sum(count) (one scalar all-reduce, no host sync)
+    so that the SUM of the ranks' gradients is the gradient of the global masked mean; allreduce_gradients() then sums
+    without dividing.  Without it, gradients are averaged (equal-count shards)."""
+
+    def __init__(self, module: torch.nn.Module, world: int | None = None, late_module: str | None = "feature_extraction"):
         self.module = module
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        named = [(k, p) for k, p in module.named_parameters() if p.requires_grad]
+        late = getattr(module, late_module, None) if late_module else None
+        late_ids = {id(p) for p in late.parameters()} if late is not None else set()
+        # bucket order: late (encoder) slice first, then the early-finishing rest -- each slice contiguous
+        named.sort(key=lambda kp: 0 if id(kp[1]) in late_ids else 1)
+        self.params = [p for _, p in named]
+        self.n_late = sum(1 for p in self.params if id(p) in late_ids)
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         self.views, off = [], 0
-        for p in self.params:
+        for i, p in enumerate(self.params):
+            if i == self.n_late:
+                self.early_off = off
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        if self.n_late == len(self.params):
+            self.early_off = off
         for p, v in zip(self.params, self.views):
             p.grad = v
+        self._sum_only = False
+        self._early_work = None
+        self._fired = 0
+        self._expected = None
+        self._side = torch.cuda.Stream(device=ref.device) if ref.is_cuda else None
+        self.overlap = self.world > 1 and late is not None and 0 < self.n_late < len(self.params)
+        if self.overlap:
+            late.register_forward_hook(self._watch_late_outputs)
         if self.world > 1:
             self.broadcast_parameters()
 
@@ -73,11 +103,37 @@ class FlatBucketDDP:
         for p in self.params:
             p.grad = None
 
-    def allreduce_gradients(self):
-        """Gather the step's gradients into the bucket, sum over ranks, average (= the gradient of the mean loss over
-        the global batch), and leave every .grad pointing at its slice of the bucket for the optimizer."""
+    # ---- loss scaling --------------------------------------------------------------------------------------------
+    def global_mean_loss(self, loss: torch.Tensor, count: torch.Tensor):
+        """loss = this rank's masked MEAN, count = its number of masked elements (device scalar, e.g. stereo_loss3's
+        metrics[1]).  Returns the loss rescaled so that summing gradients over ranks gives the gradient of the masked mean
+        over the GLOBAL batch.  A rank with an empty mask contributes nothing."""
+        if self.world == 1:
+            return loss
+        count = count.detach().to(loss.dtype)
+        total = count.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        self._sum_only = True
+        return torch.where(count > 0, loss * (count / total), torch.zeros_like(loss))
+
+    # ---- overlap ---------------------------------------------------------------------------------------------------
+    def _watch_late_outputs(self, _module, _inputs, outputs):
+        if not torch.is_grad_enabled():
+            return
+        outs = outputs if isinstance(outputs, (tuple, list)) else (outputs,)
+        for t in outs:
+            if torch.is_tensor(t) and t.requires_grad:
+                t.register_hook(self._late_output_grad)
+
+    def _late_output_grad(self, grad):
+        self._fired += 1
+        if self._expected is not None and self._fired == self._expected and self._early_work is None:
+            self._start_early()
+        return grad
+
+    def _gather(self, lo: int, hi: int):
         dst, src, unused = [], [], []
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             if p.grad is None:
                 unused.append(v)                      # parameter not reached by this step's graph
             elif p.grad.data_ptr() != v.data_ptr():
@@ -87,11 +143,41 @@ class FlatBucketDDP:
             torch._foreach_copy_(dst, src)
         if unused:
             torch._foreach_zero_(unused)
+
+    def _start_early(self):
+        """All gradients of the non-encoder slice exist: gather them and reduce them under the encoder's backward."""
+        if any(p.grad is None for p in self.params[self.n_late:]):
+            return                                    # a different graph than the one learnt: reduce everything at the end
+        self._gather(self.n_late, len(self.params))
+        for p, v in zip(self.params[self.n_late:], self.views[self.n_late:]):
+            p.grad = v
+        tail = self.flat[self.early_off:]
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self._early_work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            self._early_work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True)
+
+    def allreduce_gradients(self):
+        """Gather the step's gradients into the bucket, sum over ranks (average unless global_mean_loss pre-scaled the loss),
+        and leave every .grad pointing at its slice of the bucket for the optimizer."""
+        early_done = self._early_work is not None
+        self._gather(0, self.n_late if early_done else len(self.params))
         if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(self.world)
+            if early_done:
+                if self.n_late:
+                    dist.all_reduce(self.flat[:self.early_off], op=dist.ReduceOp.SUM)
+                self._early_work.wait()               # the current stream waits for the side-stream reduction
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if not self._sum_only:
+                self.flat.div_(self.world)
         for p, v in zip(self.params, self.views):
             p.grad = v
+        if self.overlap:
+            self._expected = self._fired if self._fired > 0 else None      # hooks per backward, learnt from this step
+        self._fired, self._early_work, self._sum_only = 0, None, False
 
     def __call__(self, *a, **k):
         return self.module(*a, **k)
@@ -103,6 +189,13 @@ def masked_smooth_l1_x3(preds, gt, maxdisp: int = 192):
     their six device->host syncs per step).  GPU tensors only, like every op of the package (no CPU fallback)."""
     from . import ops
     return ops.stereo_loss3(preds, gt, maxdisp)[0]
+
+
+def masked_smooth_l1_x3_with_count(preds, gt, maxdisp: int = 192):
+    """-> (loss, mask count as a device scalar): what FlatBucketDDP.global_mean_loss needs (no host sync)."""
+    from . import ops
+    loss, metrics = ops.stereo_loss3(preds, gt, maxdisp)
+    return loss, metrics[1]
 
 
 class GraphedForward:

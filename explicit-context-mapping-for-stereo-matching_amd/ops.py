@@ -633,23 +633,94 @@ def frame_prep(frames, crop_y0, crop_x0, th, tw, split=None, tail=0, mean=FLYING
     """Batched GPU form of Flying3d.__getitem__ + transform (cmf/loader/Flying3d.py:49-99): frames [B,H,W,7] float32
     (resident) -> left, right [B,3,th,tw] normalised, disparity [B,th,tw] (and the raw left image in CHW).
     Train: th, tw = 256, 512 and crop_y0/crop_x0 = the window origins the loader draws at random.  Eval on 540x960 frames:
-    th, tw = 576, 960, crops 0, split=540, tail=36 (the last 36 rows are appended again)."""
-    _chk(frames)
-    frames = _c(frames)
-    B, H, W, ch = frames.shape
-    if ch != 7:
-        raise RuntimeError(f"frame_prep expects [B,H,W,7] frames (left RGB, right RGB, disparity), got {tuple(frames.shape)}")
+    th, tw = 576, 960, crops 0, split=540, tail=36 (the last 36 rows are appended again).
+    `frames` may also be a packed shard: a tuple (rgb6 uint8 [B,H,W,6], disparity fp16|fp32 [B,H,W])."""
+    return _frame_prep(frames, crop_y0, crop_x0, th, tw, split, tail, mean, std, want_image, 0)
+
+
+def frame_prep_kitti_eval(frames, th=384, tw=1248, mean=FLYING3D_MEAN, std=FLYING3D_STD, want_image=False):
+    """KITTI.__getitem__'s eval branch (cmf/loader/KITTI.py:98-108): top / left repeat padding to th x tw with the
+    disparity zeroed in (and, through the loader's numpy views, next to) the padding.  `frames`: float32 [B,H,W,7] or a
+    packed shard tuple as in frame_prep."""
+    return _frame_prep(frames, None, None, th, tw, None, 0, mean, std, want_image, 1)
+
+
+def _frame_prep(frames, crop_y0, crop_x0, th, tw, split, tail, mean, std, want_image, mode):
+    packed = isinstance(frames, (tuple, list))
+    if packed:
+        rgb, dsp = frames
+        if not (rgb.is_cuda and dsp.is_cuda):
+            raise RuntimeError("ecm ops run only on the MI355X HIP path: got a CPU tensor (no CPU fallback exists)")
+        if rgb.dtype != torch.uint8 or dsp.dtype not in (torch.float16, torch.float32) or rgb.shape[-1] != 6 \
+                or tuple(rgb.shape[:3]) != tuple(dsp.shape):
+            raise RuntimeError(f"packed shard must be (uint8 [B,H,W,6], fp16|fp32 [B,H,W]), got {rgb.dtype} {tuple(rgb.shape)} / "
+                               f"{dsp.dtype} {tuple(dsp.shape)}")
+        rgb, dsp = rgb.contiguous(), dsp.contiguous()
+        B, H, W = dsp.shape
+        dev = rgb.device
+    else:
+        _chk(frames)
+        frames = _c(frames)
+        B, H, W, ch = frames.shape
+        if ch != 7:
+            raise RuntimeError(f"frame_prep expects [B,H,W,7] frames (left RGB, right RGB, disparity), got {tuple(frames.shape)}")
+        dev = frames.device
     split = th if split is None else int(split)
-    ys = (C.c_int * B)(*[int(v) for v in crop_y0])
-    xs = (C.c_int * B)(*[int(v) for v in crop_x0])
+    ys = (C.c_int * B)(*[int(v) for v in crop_y0]) if crop_y0 is not None else None
+    xs = (C.c_int * B)(*[int(v) for v in crop_x0]) if crop_x0 is not None else None
     m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
-    left = torch.empty(B, 3, th, tw, device=frames.device, dtype=frames.dtype)
+    left = torch.empty(B, 3, th, tw, device=dev, dtype=torch.float32)
     right = torch.empty_like(left)
-    disp = torch.empty(B, th, tw, device=frames.device, dtype=frames.dtype)
+    disp = torch.empty(B, th, tw, device=dev, dtype=torch.float32)
     image = torch.empty_like(left) if want_image else None
-    _lib.call("ecm_frame_prep", _p(frames), _p(left), _p(right), _p(disp), _p(image), B, H, W, ys, xs, int(th), int(tw), split,
-              int(tail), m3, s3, _stream())
+    if packed:
+        _lib.call("ecm_frame_prep_packed", _p(rgb), _p(dsp), int(dsp.dtype == torch.float16), _p(left), _p(right), _p(disp),
+                  _p(image), B, H, W, ys, xs, int(th), int(tw), split, int(tail), m3, s3, mode, _stream())
+    elif mode == 1:
+        _lib.call("ecm_frame_prep_kitti_eval", _p(frames), _p(left), _p(right), _p(disp), _p(image), B, H, W, int(th), int(tw),
+                  m3, s3, _stream())
+    else:
+        _lib.call("ecm_frame_prep", _p(frames), _p(left), _p(right), _p(disp), _p(image), B, H, W, ys, xs, int(th), int(tw),
+                  split, int(tail), m3, s3, _stream())
     return (left, right, disp, image) if want_image else (left, right, disp)
+
+
+def eval_epe(pred, gt, crop_h=540, crop_w=960, maxdisp=192):
+    """SceneFlow evaluation of test.py:69-94 on the device: pred [B,1,Hp,Wp] or [B,Hp,Wp] (output3), gt [B,Hg,Wg];
+    -> float32[6] = (epe, epe_non, epe_true, n, n_non, n_true), both tensors cropped to [:crop_h, :crop_w]."""
+    _chk(pred, gt)
+    if pred.dim() == 4:
+        pred = pred.squeeze(1)
+    pred, gt = _c(pred), _c(gt)
+    B, Hp, Wp = pred.shape
+    Bg, Hg, Wg = gt.shape
+    if B != Bg:
+        raise RuntimeError(f"prediction / ground-truth batch sizes differ: {B} vs {Bg}")
+    out = torch.empty(6, device=pred.device, dtype=torch.float32)
+    n = B * int(crop_h) * int(crop_w)
+    nb = _lib.query("ecm_eval_epe_scratch_bytes", C.c_longlong(n))
+    scratch = _scratch(nb, pred.device)
+    _lib.call("ecm_eval_epe", _p(pred), _p(gt), _p(out), _p(scratch), C.c_longlong(nb), B, Hp, Wp, Hg, Wg, int(crop_h),
+              int(crop_w), C.c_float(maxdisp), _stream())
+    return out
+
+
+def disparity_to_uint16(pred, h, w, scale=256.0):
+    """KITTI submission image of test_kitti.py:163-168: pred [B,1,Hp,Wp] or [B,Hp,Wp] (output3) -> uint16 [B,max h,max w]
+    with out[b,:h[b],:w[b]] = (pred[b,-h[b]:,-w[b]:] * scale).astype(uint16) (numpy cast semantics), zeros elsewhere.
+    h, w: per-sample original sizes (ints or sequences)."""
+    _chk(pred)
+    if pred.dim() == 4:
+        pred = pred.squeeze(1)
+    pred = _c(pred)
+    B, Hp, Wp = pred.shape
+    hs = [int(h)] * B if isinstance(h, int) else [int(v) for v in h]
+    ws = [int(w)] * B if isinstance(w, int) else [int(v) for v in w]
+    Ho, Wo = max(hs), max(ws)
+    out = torch.empty(B, Ho, Wo, device=pred.device, dtype=torch.uint16)
+    _lib.call("ecm_disp_to_u16", _p(pred), _p(out), B, Hp, Wp, (C.c_int * B)(*hs), (C.c_int * B)(*ws), Ho, Wo,
+              C.c_float(scale), _stream())
+    return out
 
 
 class StereoLoss3(torch.autograd.Function):

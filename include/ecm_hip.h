@@ -217,6 +217,35 @@ int ecm_frame_prep(const float* frames, float* left, float* right, float* disp, 
                    const int* crop_y0, const int* crop_x0, int th, int tw, int split, int tail,
                    const float* mean3, const float* std3, void* stream);
 
+/* KITTI evaluation frames (cmf/loader/KITTI.py:98-108): pad [B,H,W,7] frames to th x tw (384 x 1248) at the TOP and LEFT
+ * by repeating the first th-H rows / tw-W columns; disparity is 0 wherever the source row < th-H or the source column <
+ * tw-W (the loader zeroes it through numpy views, which also hits the un-padded frame).  Needs th-H <= H, tw-W <= W. */
+int ecm_frame_prep_kitti_eval(const float* frames, float* left, float* right, float* disp, float* image, int B,
+                              int H, int W, int th, int tw, const float* mean3, const float* std3, void* stream);
+
+/* Packed shards (frame contents per flying3ddata.py:34-39): rgb6 uint8 [B,H,W,6] (left RGB, right RGB) and
+ * disp_in [B,H,W] as fp16 (disp_is_half != 0) or fp32.  Same outputs and arithmetic as ecm_frame_prep; mode 0 = the
+ * window / split-tail form with crop_y0/crop_x0/split/tail as there, mode 1 = the KITTI top-left padding (crop arrays,
+ * split and tail ignored).  Colour outputs are bit-identical to the float32-frame path on the same pixel values. */
+int ecm_frame_prep_packed(const unsigned char* rgb6, const void* disp_in, int disp_is_half, float* left, float* right,
+                          float* disp, float* image, int B, int H, int W, const int* crop_y0, const int* crop_x0,
+                          int th, int tw, int split, int tail, const float* mean3, const float* std3, int mode, void* stream);
+
+/* SceneFlow evaluation (test.py:69-94): pred [B,Hp,Wp] (= output3 squeezed) and gt [B,Hg,Wg], both cropped to
+ * [:crop_h, :crop_w] (540 x 960).  out6 (device) = [epe, epe_non, epe_true, n, n_non, n_true]: mean |pred - gt| under
+ *   mask = 0 <= gt < maxdisp;  mask_non = mask and x - gt >= 0;  mask_true = 0 < gt < maxdisp and x - gt >= 0
+ * (x = column index).  An empty mask gives NaN like the reference's mean of an empty selection. */
+long long ecm_eval_epe_scratch_bytes(long long n);
+int ecm_eval_epe(const float* pred, const float* gt, float* out6, void* scratch, long long scratch_bytes, int B,
+                 int Hp, int Wp, int Hg, int Wg, int crop_h, int crop_w, float maxdisp, void* stream);
+
+/* KITTI submission image (test_kitti.py:163-168): out[b,y,x] = (uint16)(pred[b, Hp-h[b]+y, Wp-w[b]+x] * scale) for
+ * y < h[b], x < w[b] (the loader padded at the top and left), 0 elsewhere; scale = 256.  The cast is numpy's on the
+ * reference's host: truncation toward zero, low 16 bits of the 32-bit integer, 0 for NaN / out-of-int32-range values.
+ * pred: [B,Hp,Wp]; out: uint16 [B,Ho,Wo]; h, w: HOST arrays of B ints.  Integer output: bit-exact. */
+int ecm_disp_to_u16(const float* pred, unsigned short* out, int B, int Hp, int Wp, const int* h, const int* w,
+                    int Ho, int Wo, float scale, void* stream);
+
 /* Harness loss + metrics (train.py:162,172-174; train_kitti.py:205-216) over n = B*H*W pixels; mask = 0 < gt < maxdisp.
  * out8 (device): [loss, #mask, epe(p3), err3(p3) in %, mean smooth-L1 of p1, p2, p3, 0];
  * loss = w1*m1 + w2*m2 + w3*m3 (reference weights 0.5 / 0.7 / 1.0).  Empty mask -> NaN (as the reference's empty mean).

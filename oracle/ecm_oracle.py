@@ -338,6 +338,65 @@ def kitti_metrics(pred3, gt, maxdisp=192):
     return epe, 100 - torch.sum(good) / torch.sum(mask) * 100
 
 
+# ----------------------------------------------------------------------------
+# Eval leg of the harness: test.py:69-94, test_kitti.py:163-168, KITTI.py:98-108
+# Pinned by tests/golden/g9_eval_harness.npz, which make_golden.py produces by EXECUTING those reference lines.
+# ----------------------------------------------------------------------------
+def sceneflow_eval_epe(output3, disparity, maxdisp=192):
+    """test.py:69-94: crop ground truth and prediction to [:540,:960], three masks, mean |error| under each.
+    output3 [B,1,H,W] (or [B,H,W]), disparity [B,Hg,Wg] -> (loss, loss_non, loss_true) as python floats."""
+    disparity = disparity[:, :540, :960]                                                        # :69
+    local = torch.arange(disparity.shape[-1]).repeat(disparity.shape[0], disparity.shape[1], 1).view_as(disparity).float()  # :70
+    mask_non = (disparity < maxdisp) & (disparity >= 0) & ((local - disparity) >= 0)           # :71
+    mask_true = (disparity < maxdisp) & (disparity > 0) & ((local - disparity) >= 0)           # :72
+    mask = (disparity < maxdisp) & (disparity >= 0)                                             # :73
+    o = output3.squeeze(1) if output3.dim() == 4 else output3
+    o = o[:, :540, :960]                                                                        # :83
+    loss = torch.mean(torch.abs(o[mask] - disparity[mask]))                                     # :92
+    loss_non = torch.mean(torch.abs(o[mask_non] - disparity[mask_non]))                         # :93
+    loss_true = torch.mean(torch.abs(o[mask_true] - disparity[mask_true]))                      # :94
+    return loss.item(), loss_non.item(), loss_true.item()
+
+
+def kitti_disparity_uint16(output3, h, w):
+    """test_kitti.py:163-168 for sample 0: output3*256 -> numpy uint16 (C cast), un-pad the top/left padding."""
+    import numpy as np
+    o = output3.squeeze(1) if output3.dim() == 4 else output3
+    pre = (o * 256).data.cpu().numpy().astype("uint16")                                         # :163-164
+    pre = pre[0, -h:, -w:]                                                                      # :165
+    return np.reshape(pre, [h, w])                                                              # :168
+
+
+def kitti_eval_pad(frame, th=384, tw=1248):
+    """KITTI.__getitem__, eval branch (cmf/loader/KITTI.py:98-108) on one [H,W,7] frame.  `padding_h` / `padding_w` are
+    numpy VIEWS, so zeroing their disparity channel also zeroes it in the array they were cut from -- kept as is.
+    Returns the padded [th,tw,7] array (the caller's `frame` is modified like the loader's `data`)."""
+    import numpy as np
+    data = frame
+    h, w = data.shape[0], data.shape[1]                                                         # :99
+    padding_h = data[:(th - h), :, :]                                                           # :103
+    padding_h[:, :, 6] = 0                                                                      # :104
+    data = np.concatenate([padding_h, data], 0)                                                 # :105
+    padding_w = data[:, :(tw - w), :]                                                           # :106
+    padding_w[:, :, 6] = 0                                                                      # :107
+    return np.concatenate([padding_w, data], 1)                                                 # :108
+
+
+def kitti_eval_sample(frame, th=384, tw=1248):
+    """KITTI.__getitem__ eval branch + transform (KITTI.py:98-126): -> (left, right [3,th,tw], disparity [th,tw]); the
+    ToTensor / Normalize semantics are restated as in flying3d_sample (torchvision is absent: unpinned for those two)."""
+    import numpy as np
+    data = kitti_eval_pad(np.array(frame, copy=True), th, tw)
+    mean = torch.tensor(FLYING3D_MEAN, dtype=torch.float32)[:, None, None]                      # KITTI.py:54-55: same stats
+    std = torch.tensor(FLYING3D_STD, dtype=torch.float32)[:, None, None]
+
+    def trans(a):
+        t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+        return ((t - mean.to(t.dtype)) / std.to(t.dtype)).float()
+
+    return trans(data[..., 0:3] / 255), trans(data[..., 3:6] / 255), torch.from_numpy(np.ascontiguousarray(data[..., 6])).float()
+
+
 # ============================================================================
 # The other registered architectures (SURVEY 8a rows a4, a10, a11)
 # ============================================================================

@@ -43,3 +43,25 @@ def make_state_dict(shapes: dict) -> dict:
 def seeded(name: str, *shape, scale: float = 1.0) -> torch.Tensor:
     """A named deterministic input tensor."""
     return torch.randn(*shape, generator=_gen("input:" + name)) * scale
+
+
+def eval_harness_inputs():
+    """Deterministic inputs of the eval-harness fixture g9 (tests/golden/make_golden_eval.py and the tests that check it
+    build the SAME tensors from this function; only the reference's outputs are stored in the fixture)."""
+    import numpy as np
+    g = torch.Generator().manual_seed(9)
+    B, H, W = 2, 576, 960
+    disp = torch.rand(B, H, W, generator=g) * 260.0 - 20.0          # some values < 0 and >= 192: every mask edge is hit
+    disp[0, :50, :40] = 0.0                                          # d == 0 separates mask / mask_true
+    disp[1, 100:140, :] = 191.99
+    disp[:, :, :8] = disp[:, :, :8].abs() + 3.0                      # x - d < 0 near the left border
+    out3 = (disp + torch.randn(B, H, W, generator=g) * 2.0).unsqueeze(1)
+    h, w = 375, 1242
+    o3k = torch.rand(1, 1, 384, 1248, generator=g) * 191.0
+    edge = torch.tensor([0.0, 0.00390625, 0.0039, 1.0, 255.99609375, 255.998, 256.0, 300.0, -0.001, -0.5, -1.0, -2.75,
+                         1e6, -1e6, 8388607.5, 3e9, -3e9, float("nan"), float("inf"), float("-inf"), 191.999, 0.999,
+                         2.0 ** -10, 100.5])
+    o3k[0, 0, 9:12, 6:30] = edge.view(1, 24).expand(3, 24)           # inside the un-padded 375 x 1242 window
+    frame = np.concatenate([np.random.RandomState(9).randint(0, 256, size=(h, w, 6)).astype(np.float32),
+                            (np.random.RandomState(10).rand(h, w, 1) * 200.0).astype(np.float32)], 2)
+    return dict(sf_disparity=disp, sf_output3=out3, kitti_output3=o3k, kitti_hw=(h, w), kitti_frame=frame)

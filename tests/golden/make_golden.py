@@ -240,4 +240,5 @@ for k, p in model.named_parameters():
         g8["gn_" + k.replace(".", "_")] = p.grad.norm()
         g8["g_" + k.replace(".", "_")] = p.grad.clone()          # the full tensor: a norm cannot see a permuted gradient
 save("g8_full_cmfsm_256x512", **g8)
+
 print("done")

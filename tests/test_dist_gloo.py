@@ -63,6 +63,92 @@ def test_flat_bucket_allreduce_two_ranks():
     torch.testing.assert_close(r0["params"], r1["params"], rtol=0, atol=0)
 
 
+class _TwoStage(torch.nn.Module):
+    """An `enc` whose outputs feed a `head`, like feature_extraction -> hot path: backward finishes `head` first."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(11)
+        self.enc = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.GroupNorm(4, 8), torch.nn.ReLU())
+        self.head = torch.nn.Sequential(torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 1, 3, padding=1))
+        self.head_scale = torch.nn.Parameter(torch.ones(1))
+
+    def forward(self, x):
+        return self.head(self.enc(x)) * self.head_scale
+
+
+def _masked_mean_loss(pred, gt):
+    """The shape of train.py:162,172: a mean over the masked pixels only; also returns the mask count."""
+    mask = (gt > 0) & (gt < 192)
+    return torch.nn.functional.smooth_l1_loss(pred[mask], gt[mask], reduction="mean"), mask.sum().to(pred.dtype)
+
+
+def _batch():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    gt = torch.rand(4, 1, 8, 8, generator=g) * 191.0 + 0.5
+    gt[0, :, :6] = 0.0           # very different mask counts per sample -> per rank
+    gt[1, :, :1] = 250.0
+    gt[3] = 0.0                  # a sample with an EMPTY mask
+    gt[3, 0, 7, 7] = 10.0
+    return x, gt
+
+
+def _worker_masked(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from importlib import import_module
+    D = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
+    D.init_from_env("gloo")
+    model = _TwoStage()
+    ddp = D.FlatBucketDDP(model, world, late_module="enc")
+    assert ddp.overlap and 0 < ddp.n_late < len(ddp.params)
+    x, gt = _batch()
+    idx = list(D.shard_batch(4, rank, world))
+    rec = []
+    for step in range(3):        # step 0 learns the hook count; steps 1, 2 take the overlapped path
+        ddp.zero_grad()
+        loss, cnt = _masked_mean_loss(model(x[idx]), gt[idx])
+        ddp.global_mean_loss(loss, cnt).backward()
+        took_early = ddp._early_work is not None
+        ddp.allreduce_gradients()
+        rec.append((took_early, ddp.flat.clone()))
+    assert [r[0] for r in rec] == [False, True, True], [r[0] for r in rec]
+    names = [k for k, p in model.named_parameters()]
+    order = {id(p): k for k, p in model.named_parameters()}
+    torch.save({"grads": [r[1] for r in rec], "order": [order[id(p)] for p in ddp.params], "names": names},
+               os.path.join(out_dir, f"m{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_global_masked_mean_and_overlapped_slices_two_ranks():
+    """Unequal mask counts per rank (incl. an almost-empty sample): the summed gradients must equal the gradient of the
+    reference's ONE masked mean over the global batch (train.py:162-174 after DataParallel's gather) -- on the plain path
+    (first step) and on the path that reduces the non-encoder slice early, under the encoder's backward."""
+    port = 31500 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_masked, args=(2, port, d), nprocs=2, join=True)
+        r0, r1 = torch.load(os.path.join(d, "m0.pt")), torch.load(os.path.join(d, "m1.pt"))
+    model = _TwoStage()
+    x, gt = _batch()
+    loss, _ = _masked_mean_loss(model(x), gt)
+    loss.backward()
+    byname = dict(model.named_parameters())
+    ref = torch.cat([byname[k].grad.flatten() for k in r0["order"]])
+    assert r0["order"][0].startswith("enc.") and r0["order"][-1].startswith("head")       # encoder slice first
+    for a, b in zip(r0["grads"], r1["grads"]):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
+        torch.testing.assert_close(a, ref, rtol=1e-5, atol=1e-7)
+    # and it is NOT what averaging per-rank means would give (the round-1 behaviour) -- the test can tell them apart
+    la, _ = _masked_mean_loss(model(x[:2]), gt[:2])
+    lb, _ = _masked_mean_loss(model(x[2:]), gt[2:])
+    model.zero_grad()
+    ((la + lb) / 2).backward()
+    avg = torch.cat([byname[k].grad.flatten() for k in r0["order"]])
+    assert (avg - ref).abs().max() > 1e-3 * ref.abs().max()
+
+
 def test_shard_batch_covers_everything():
     sys.path.insert(0, ROOT)
     from importlib import import_module

@@ -2,7 +2,9 @@
 (tests/golden/make_golden.py).  Pins the oracle before anything is compared with it."""
 import torch
 
-from conftest import load_golden
+import os
+
+from conftest import GOLDEN, load_golden
 from oracle import ecm_oracle as O
 from oracle.weights import seeded
 
@@ -199,3 +201,32 @@ def test_flying3d_sample_restatement():
     assert float(D[10, 123]) == 123.0 and float(D[575, 3]) == 7.0 and float(D[539, 3]) == 7.0      # padded rows = last 36
     L2, _, D2, _ = O.flying3d_sample(fr, "train", (100, 200))
     assert L2.shape == (3, 256, 512) and float(D2[0, 0]) == 200.0
+
+
+# ------------------------------------------------------------------ eval leg of the harness (row H), fixture g9
+def test_g9_eval_harness_restatements():
+    """oracle.sceneflow_eval_epe / kitti_disparity_uint16 / kitti_eval_pad against the outputs of the reference's own
+    statements (test.py:66-94, test_kitti.py:158-168, KITTI.py:99-108; executed by tests/golden/make_golden_eval.py)."""
+    import hashlib
+    import warnings
+    import numpy as np
+    from oracle.weights import eval_harness_inputs
+    with np.load(os.path.join(GOLDEN, "g9_eval_harness.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    inp = eval_harness_inputs()
+    epe = O.sceneflow_eval_epe(inp["sf_output3"], inp["sf_disparity"])
+    np.testing.assert_allclose(np.array(epe), g["epe"][:3], rtol=1e-6)
+    h, w = inp["kitti_hw"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        u16 = O.kitti_disparity_uint16(inp["kitti_output3"], h, w)
+    assert u16.dtype == np.uint16 and u16.shape == (h, w)
+    assert hashlib.sha256(np.ascontiguousarray(u16).tobytes()).digest() == g["u16_sha256"].tobytes()
+    assert np.array_equal(u16[:8], g["u16_head"]) and np.array_equal(u16[::5, ::5], g["u16_sub"])
+    pad = O.kitti_eval_pad(inp["kitti_frame"].copy())
+    assert pad.shape == (384, 1248, 7)
+    assert np.array_equal(np.packbits(pad[..., 6] != 0), g["pad_disp_nonzero"])
+    assert np.array_equal(pad[::3, ::5, 6], g["pad_disp_sub"])
+    assert np.array_equal(pad[::7, ::11, :6].astype(np.uint8), g["pad_rgb_sub"])
+    assert np.array_equal(pad[..., :6].sum(axis=(1, 2), dtype=np.float64), g["pad_rgb_rowsum"])
+    assert np.array_equal(pad[..., :6].sum(axis=(0, 2), dtype=np.float64), g["pad_rgb_colsum"])

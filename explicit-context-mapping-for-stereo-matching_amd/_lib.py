@@ -51,6 +51,13 @@ PROTOTYPES = {
     "ecm_conv2d_k3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ecm_conv2d_k3_wgrad_scratch_bytes": (_LL, [_I] * 5),
     "ecm_conv2d_k3_wgrad": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
+    "ecm_conv2d_packed_floats_ex": (_LL, [_I] * 4),
+    "ecm_conv2d_pack_weight_ex": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "ecm_conv2d_fwd_ex": (_I, [_P, _P, _P] + [_I] * 13 + [_P]),
+    "ecm_conv2d_wgrad_ex_scratch_bytes": (_LL, [_I] * 8),
+    "ecm_conv2d_wgrad_ex": (_I, [_P, _P, _P, _P, _LL] + [_I] * 13 + [_P]),
+    "ecm_deconv2d_pack_weight": (_I, [_P, _P, _I, _I, _P]),
+    "ecm_deconv2d_k3s2_fwd": (_I, [_P, _P, _P] + [_I] * 7 + [_P]),
     "ecm_stereo_loss_scratch_bytes": (_LL, [_LL]),
     "ecm_stereo_loss_fwd": (_I, [_P] * 6 + [_LL, _LL, _F, _F, _F, _F, _P]),
     "ecm_stereo_loss_bwd": (_I, [_P] * 9 + [_LL, _F, _F, _F, _F, _P]),

@@ -28,13 +28,19 @@ constexpr int TWV = 16;       // output voxels per tile row
 
 // KD = 3: the 3x3x3 Conv3d.  KD = 1: a 3x3 Conv2d seen as a depth-1 volume with no taps and no padding along depth
 // (the encoder's convbn, cmfsm.py:37-47) -- same staging, 9 taps.
-template <int STRIDE, int TD, int TH, int KD>
+// KH x KW taps with dilation DIL in the plane (KD = 1 only: the encoder's dilated / strided / 1x1 layers and the sheared
+// 3x5 class convolution of the collapsed cost volume, conv2d.hip); the 3-D layers are always 3x3x3, dilation 1.
+template <int STRIDE, int TD, int TH, int KD, int KH = 3, int KW = 3, int DIL = 1>
 struct WgCfg {
-    static constexpr int NTAPS = 9 * KD, PADD = KD / 2;
-    // wave plan: KD=3 -> 4 tap groups of 7 (the last has 6), every wave runs all k-steps;
-    //            KD=1 -> 2 tap groups (5 + 4) x 2 halves of the k-steps (each half writes its own partial).
-    static constexpr int TG = KD == 3 ? 4 : 2, KG = 4 / TG, MAXNT = KD == 3 ? 7 : 5;
-    static constexpr int ID = (TD - 1) * STRIDE + KD, IH = (TH - 1) * STRIDE + 3, IW = (TWV - 1) * STRIDE + 3;
+    static_assert(KD == 1 || (KH == 3 && KW == 3 && DIL == 1), "3-D layers are 3x3x3, dilation 1");
+    static constexpr int NTAPS = KH * KW * KD, PADD = KD / 2;
+    // wave plan: 27 taps -> 4 tap groups of 7 (the last has 6), every wave runs all k-steps;
+    //            15 taps -> 4 tap groups of 4 (the last has 3);  9 taps -> 2 tap groups (5 + 4) x 2 halves of the k-steps
+    //            (each half writes its own partial);
+    //            1 tap -> 4 quarters of the k-steps.
+    static constexpr int TG = NTAPS >= 15 ? 4 : NTAPS >= 2 ? 2 : 1, KG = 4 / TG, MAXNT = (NTAPS + TG - 1) / TG;
+    static constexpr int ID = (TD - 1) * STRIDE + KD, IH = (TH - 1) * STRIDE + (KH - 1) * DIL + 1,
+                         IW = (TWV - 1) * STRIDE + (KW - 1) * DIL + 1;
     static constexpr int RS = IW;
     static constexpr int XCH = ID * IH * RS;
     static constexpr int XSTR = (XCH % 2 == 0) ? XCH + 1 : XCH + 2; // odd => 32 lanes (ci) hit 32 banks; slot XCH is a pad
@@ -51,21 +57,22 @@ struct WgCfg {
 // reads back next to their use (left to itself it waits lgkmcnt(0) in front of each MFMA group).
 // The NEXT tile's global loads are spread over the k-steps too (issue(i), i < NLOADS): issued in one burst they
 // stall the wave on the 64-entry vmcnt window for ~13K cycles per tile with the matrix core idle (measured 17.6 %).
-template <int STRIDE, int TD, int TH, int KD, int TGI, int KGI, int NLOADS, class Issue>
+template <int STRIDE, int TD, int TH, int KD, int KH, int KW, int DIL, int TGI, int KGI, int NLOADS, class Issue>
 __device__ __forceinline__ void wg_tile(const float* __restrict__ ga, const float* __restrict__ xb,
-                                        f32x16 (&acc)[WgCfg<STRIDE, TD, TH, KD>::MAXNT], Issue&& issue) {
-    using Cfg = WgCfg<STRIDE, TD, TH, KD>;
+                                        f32x16 (&acc)[WgCfg<STRIDE, TD, TH, KD, KH, KW, DIL>::MAXNT], Issue&& issue) {
+    using Cfg = WgCfg<STRIDE, TD, TH, KD, KH, KW, DIL>;
     constexpr int IH = Cfg::IH, RS = Cfg::RS;
     constexpr int T0 = TGI * Cfg::MAXNT;                                         // this wave's taps [T0, T0+NT)
     constexpr int NT = (T0 + Cfg::MAXNT <= Cfg::NTAPS) ? Cfg::MAXNT : Cfg::NTAPS - T0;
+    static_assert(NT >= 1, "every wave owns at least one tap");
     constexpr int KSA = TD * TH * TWV / 2;
     constexpr int KS0 = KGI * (KSA / Cfg::KG), KS = KS0 + KSA / Cfg::KG;         // this wave's k-steps [KS0, KS)
     constexpr int KSI = (KS - KS0) * 3 / 4;                   // all issued within the first 3/4 of the k-steps, so that
     constexpr int LPK = (NLOADS + KSI - 1) / KSI;             // their latency is not exposed at the LDS stores that follow
     auto b_off = [](int ks, int t) constexpr {
         const int xx = (ks * 2) % TWV, hy = ((ks * 2) / TWV) % TH, dz = (ks * 2) / (TWV * TH);
-        const int tap = T0 + t, kd = KD == 3 ? tap / 9 : 0, kh = (tap / 3) % 3, kw = tap % 3;
-        return ((dz * STRIDE + kd) * IH + hy * STRIDE + kh) * RS + xx * STRIDE + kw;
+        const int tap = T0 + t, kd = KD == 3 ? tap / 9 : 0, kh = (tap / KW) % KH, kw = tap % KW;
+        return ((dz * STRIDE + kd) * IH + hy * STRIDE + kh * DIL) * RS + xx * STRIDE + kw * DIL;
     };
     float a_cur = ga[KS0 * 2], b_cur[NT];
 #pragma unroll
@@ -90,12 +97,12 @@ __device__ __forceinline__ void wg_tile(const float* __restrict__ ga, const floa
     }
 }
 
-template <int STRIDE, int TD, int TH, int KD>
+template <int STRIDE, int TD, int TH, int KD, int KH = 3, int KW = 3, int DIL = 1>
 __global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
                                                          float* __restrict__ partial, int B, int Ci, int Co, int D,
                                                          int H, int W, int Do, int Ho, int Wo, int tiles_d, int tiles_h,
-                                                         int tiles_w, int ci_tiles) {
-    using Cfg = WgCfg<STRIDE, TD, TH, KD>;
+                                                         int tiles_w, int ci_tiles, int pad_top, int pad_left) {
+    using Cfg = WgCfg<STRIDE, TD, TH, KD, KH, KW, DIL>;
     constexpr int ID = Cfg::ID, IH = Cfg::IH, IW = Cfg::IW, XSTR = Cfg::XSTR, NV = Cfg::NV, GSTR = Cfg::GSTR,
                   NTAPS = Cfg::NTAPS, MAXNT = Cfg::MAXNT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const 
         const int th = (int)(r % (unsigned)tiles_h);
         const int b = (int)(r / (unsigned)tiles_h);
         const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TWV;
-        const int id0 = od0 * STRIDE - Cfg::PADD, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
+        const int id0 = od0 * STRIDE - Cfg::PADD, ih0 = oh0 * STRIDE - pad_top, iw0 = ow0 * STRIDE - pad_left;
         const int xbase = id0 * (int)HWi + ih0 * W + iw0;
 #pragma unroll
         for (int j = 0; j < PPX; ++j) {
@@ -219,10 +226,10 @@ __global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const 
         const float* ga = Gs + l31 * GSTR + half;
         const float* xb = Xs + l31 * XSTR + half * STRIDE;
         switch (wave) {          // wave-uniform: makes every tap offset a compile-time immediate
-            case 0: wg_tile<STRIDE, TD, TH, KD, 0 % Cfg::TG, 0 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
-            case 1: wg_tile<STRIDE, TD, TH, KD, 1 % Cfg::TG, 1 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
-            case 2: wg_tile<STRIDE, TD, TH, KD, 2 % Cfg::TG, 2 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
-            default: wg_tile<STRIDE, TD, TH, KD, 3 % Cfg::TG, 3 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            case 0: wg_tile<STRIDE, TD, TH, KD, KH, KW, DIL, 0 % Cfg::TG, 0 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            case 1: wg_tile<STRIDE, TD, TH, KD, KH, KW, DIL, 1 % Cfg::TG, 1 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            case 2: wg_tile<STRIDE, TD, TH, KD, KH, KW, DIL, 2 % Cfg::TG, 2 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
+            default: wg_tile<STRIDE, TD, TH, KD, KH, KW, DIL, 3 % Cfg::TG, 3 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
         }
         WG_T(5);
     }
@@ -283,22 +290,24 @@ inline int wgrad_workers(int Ci, int Co, long long ntiles, int occ = 1) {
     return (int)p;
 }
 
-template <int STRIDE, int TD, int TH, int KD>
+template <int STRIDE, int TD, int TH, int KD, int KH = 3, int KW = 3, int DIL = 1>
 int launch_wgrad(const float* x, const float* gy, float* gw, float* partial, int B, int Ci, int Co, int D, int H, int W,
-                 hipStream_t st) {
-    using Cfg = WgCfg<STRIDE, TD, TH, KD>;
-    const int Do = (D - 1) / STRIDE + 1, Ho = (H - 1) / STRIDE + 1, Wo = (W - 1) / STRIDE + 1;
+                 hipStream_t st, int Ho = 0, int Wo = 0, int pad_top = 1, int pad_left = 1) {
+    using Cfg = WgCfg<STRIDE, TD, TH, KD, KH, KW, DIL>;
+    const int Do = (D - 1) / STRIDE + 1;
+    if (Ho <= 0) Ho = (H - 1) / STRIDE + 1;
+    if (Wo <= 0) Wo = (W - 1) / STRIDE + 1;
     const int tiles_d = (Do + TD - 1) / TD, tiles_h = (Ho + TH - 1) / TH, tiles_w = (Wo + TWV - 1) / TWV;
     const long long ntiles = (long long)B * tiles_d * tiles_h * tiles_w;
     const int ci_tiles = (Ci + CT - 1) / CT, co_tiles = (Co + CT - 1) / CT;
     const int P = wgrad_workers(Ci, Co, ntiles, KD == 3 ? 1 : 2);
-    auto kern = conv3d_wgrad_mfma<STRIDE, TD, TH, KD>;
+    auto kern = conv3d_wgrad_mfma<STRIDE, TD, TH, KD, KH, KW, DIL>;
     {
         const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3(P, ci_tiles * co_tiles), dim3(256), Cfg::LDS_BYTES, st, x, gy, partial, B, Ci, Co, D, H,
-                       W, Do, Ho, Wo, tiles_d, tiles_h, tiles_w, ci_tiles);
+                       W, Do, Ho, Wo, tiles_d, tiles_h, tiles_w, ci_tiles, pad_top, pad_left);
     const int n = Co * Ci * Cfg::NTAPS;
     hipLaunchKernelGGL(wgrad_reduce, dim3((n + 31) / 32), dim3(256), 0, st, partial, gw, n, P * Cfg::KG);
     return ECM_LAUNCH_RESULT();
@@ -347,4 +356,40 @@ extern "C" int ecm_conv2d_k3_wgrad(const float* x, const float* gy, float* gw, v
     if (ntiles2d(B, H, W) >= 0x7fffffffLL) return ECM_EUNSUP;
     if (scratch_bytes < ecm_conv2d_k3_wgrad_scratch_bytes(B, Ci, Co, H, W)) return ECM_ESCRATCH;
     return launch_wgrad<1, 1, 16, 1>(x, gy, gw, static_cast<float*>(scratch), B, Ci, Co, 1, H, W, ecm_stream(stream));
+}
+
+// ---- general 2-D weight gradient: KH x KW in {3x3, 3x5, 1x1}, stride 1|2, dilation 1|2|4, explicit padding / output size
+namespace {
+inline long long ntiles2d_ex(int B, int Ho, int Wo, int stride) {
+    const int th = stride == 1 ? 16 : 8;
+    return (long long)B * ((Ho + th - 1) / th) * ((Wo + TWV - 1) / TWV);
+}
+}  // namespace
+
+extern "C" long long ecm_conv2d_wgrad_ex_scratch_bytes(int B, int Ci, int Co, int Ho, int Wo, int kh, int kw, int stride) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || Ho <= 0 || Wo <= 0 || kh <= 0 || kw <= 0) return 0;
+    // every worker writes KG <= 4 partials of [Co][Ci][taps]
+    return (long long)wgrad_workers(Ci, Co, ntiles2d_ex(B, Ho, Wo, stride), 2) * 4 * Co * Ci * kh * kw * (long long)sizeof(float);
+}
+
+extern "C" int ecm_conv2d_wgrad_ex(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B,
+                                   int Ci, int Co, int H, int W, int kh, int kw, int stride, int dil, int pad_top,
+                                   int pad_left, int Ho, int Wo, void* stream) {
+    ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && Co > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0);
+    if ((long long)H * W * 4 * 32 >= 0x7fffffffLL || (long long)Ho * Wo * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;
+    if (ntiles2d_ex(B, Ho, Wo, stride) >= 0x7fffffffLL) return ECM_EUNSUP;
+    if (scratch_bytes < ecm_conv2d_wgrad_ex_scratch_bytes(B, Ci, Co, Ho, Wo, kh, kw, stride)) return ECM_ESCRATCH;
+    float* partial = static_cast<float*>(scratch);
+    hipStream_t st = ecm_stream(stream);
+#define WG2(KH, KW, S, DL, TH) if (kh == KH && kw == KW && stride == S && dil == DL) \
+        return launch_wgrad<S, 1, TH, 1, KH, KW, DL>(x, gy, gw, partial, B, Ci, Co, 1, H, W, st, Ho, Wo, pad_top, pad_left)
+    WG2(3, 3, 1, 1, 16);
+    WG2(3, 3, 1, 2, 16);
+    WG2(3, 3, 1, 4, 16);
+    WG2(3, 3, 2, 1, 8);
+    WG2(3, 5, 1, 1, 16);
+    WG2(1, 1, 1, 1, 16);
+    WG2(1, 1, 2, 1, 8);
+#undef WG2
+    return ECM_EUNSUP;
 }

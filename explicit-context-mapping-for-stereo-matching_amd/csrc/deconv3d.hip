@@ -18,26 +18,28 @@ constexpr int TW = 32;
 // once per channel chunk and every one of the 27 taps issues exactly one MFMA per k-step into the accumulator of the
 // class it belongs to (so the MFMA count equals a stride-1 conv on the input grid and no class is staging-bound).
 // Waves: 4 input rows x CO_TILES output-channel tiles (256 or 512 threads); 8 classes x 16 accumulator registers each.
-template <int CO_TILES, int CIC>
+// KD = 1: the 2-D form (a depth-1 volume without taps along depth): 9 taps, 4 parity classes -- the data gradient of the
+// encoder's stride-2 3x3 Conv2d layers (cmfsm.py:141, layer2's first block).
+template <int CO_TILES, int CIC, int KD = 3>
 struct DeconvCfg {
-    static constexpr int TD = 1, TH = 4;
-    static constexpr int ID = TD + 1, IH = TH + 1, IW = TW + 1;
+    static constexpr int TD = 1, TH = 4, NTAPS = 9 * KD;
+    static constexpr int ID = KD == 3 ? TD + 1 : 1, IH = TH + 1, IW = TW + 1;
     static constexpr int RS = IW;
     static constexpr int COP = CO_TILES * 32;
     static constexpr int THREADS = 256 * CO_TILES;
     static constexpr int XS_FLOATS = CIC * ID * IH * RS;
-    static constexpr int WS_FLOATS = 27 * CIC * COP;
+    static constexpr int WS_FLOATS = NTAPS * CIC * COP;
     static constexpr int LDS_BYTES = (XS_FLOATS + 2 * WS_FLOATS) * 4;
 };
 
-template <int CO_TILES, int CIC>
+template <int CO_TILES, int CIC, int KD = 3>
 __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                                      float* __restrict__ y, int Ci, int Co, int D, int H,
                                                                      int W, int Do, int Ho, int Wo, int tiles_d, int tiles_h,
                                                                      int tiles_w) {
-    using Cfg = DeconvCfg<CO_TILES, CIC>;
+    using Cfg = DeconvCfg<CO_TILES, CIC, KD>;
     constexpr int TD = Cfg::TD, TH = Cfg::TH, ID = Cfg::ID, IH = Cfg::IH, IW = Cfg::IW, RS = Cfg::RS, COP = Cfg::COP,
-                  NTHR = Cfg::THREADS;
+                  NTHR = Cfg::THREADS, NTAPS = Cfg::NTAPS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                        // [CIC][ID][IH][RS]
     float* Ws = smem + Cfg::XS_FLOATS;       // 2 x [27][CIC][COP]
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float
 
     constexpr int NPOS = ID * IH * IW;
     constexpr int PP = (NPOS + NTHR - 1) / NTHR;
-    constexpr int NWQ = (27 * CIC * COP / 4 + NTHR - 1) / NTHR;
+    constexpr int NWQ = (NTAPS * CIC * COP / 4 + NTHR - 1) / NTHR;
     float xr[CIC * PP];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float
 #pragma unroll
         for (int i = 0; i < NWQ; ++i) {
             const int e = tid + i * NTHR;
-            if (e < 27 * CIC * COP / 4) {
+            if (e < NTAPS * CIC * COP / 4) {
                 const int tap = e / (CIC * COP / 4), r = e - tap * (CIC * COP / 4);
                 const float* src = wp + ((size_t)tap * Ci + c0) * COP + (size_t)r * 4;
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wdst + (wave_u * 64 + i * NTHR) * 4), 16, 0, 0);
@@ -119,9 +121,9 @@ __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float
         const float* Wc = Ws + buf * Cfg::WS_FLOATS;
         if (c0 + CIC < Ci) prefetch(c0 + CIC, Ws + (buf ^ 1) * Cfg::WS_FLOATS);
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
+        for (int tap = 0; tap < NTAPS; ++tap) {
             // tap k of an output of parity p reads input m + (k == 0 ? 1 : 0); k == 1 <-> even output, k in {0,2} <-> odd
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int kd = KD == 3 ? tap / 9 : 1, kh = (tap / 3) % 3, kw = tap % 3;
             const int pd = kd != 1, ph = kh != 1, pw = kw != 1;
             const int sd = kd == 0, sh = kh == 0, sw = kw == 0;
             const int cls = (pd * 2 + ph) * 2 + pw;
@@ -152,24 +154,25 @@ __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float
     }
 }
 
-// [A][Bc][27] (ConvTranspose3d [Ci,Co,27], or a Conv3d weight [Co_f,Ci_f,27] whose dgrad is wanted) -> [27][A][BcP]
-__global__ void pack_deconv_weight(const float* __restrict__ w, float* __restrict__ packed, int A, int Bc, int bcp) {
+// [A][Bc][taps] (ConvTranspose3d [Ci,Co,27], or a Conv3d / Conv2d weight [Co_f,Ci_f,27 | 9] whose dgrad is wanted)
+// -> [taps][A][BcP]
+__global__ void pack_deconv_weight(const float* __restrict__ w, float* __restrict__ packed, int A, int Bc, int bcp, int taps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 27 * A * bcp) return;
+    if (i >= taps * A * bcp) return;
     const int o = i % bcp;
     const int k = (i / bcp) % A;
     const int tap = i / (bcp * A);
-    packed[i] = o < Bc ? w[((size_t)k * Bc + o) * 27 + tap] : 0.f;
+    packed[i] = o < Bc ? w[((size_t)k * Bc + o) * taps + tap] : 0.f;
 }
 
-template <int CO_TILES, int CIC>
+template <int CO_TILES, int CIC, int KD = 3>
 int launch_deconv(const float* x, const float* wp, float* y, int B, int Ci, int Co, int D, int H, int W, int Do, int Ho,
                   int Wo, hipStream_t st) {
-    using Cfg = DeconvCfg<CO_TILES, CIC>;
+    using Cfg = DeconvCfg<CO_TILES, CIC, KD>;
     const int tiles_d = (D + Cfg::TD - 1) / Cfg::TD, tiles_h = (H + Cfg::TH - 1) / Cfg::TH, tiles_w = (W + TW - 1) / TW;
     const long long nblk = (long long)B * tiles_d * tiles_h * tiles_w;
     if (nblk > 0x7fffffffLL || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
-    auto kern = deconv3d_k3s2_mfma<CO_TILES, CIC>;
+    auto kern = deconv3d_k3s2_mfma<CO_TILES, CIC, KD>;
     {
         const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
@@ -186,7 +189,7 @@ extern "C" int ecm_deconv3d_pack_weight(const float* w, float* packed, int Ci, i
     const int cop = ((Co + 31) / 32) * 32;
     const int n = 27 * Ci * cop;
     hipLaunchKernelGGL(pack_deconv_weight, dim3((n + 255) / 256), dim3(256), 0, ecm_stream(stream), w, packed, Ci, Co,
-                       cop);
+                       cop, 27);
     return ECM_LAUNCH_RESULT();
 }
 
@@ -199,4 +202,24 @@ extern "C" int ecm_deconv3d_k3s2_fwd(const float* x, const float* wpacked, float
     hipStream_t st = ecm_stream(stream);
     if (Co > 32) return launch_deconv<2, 4>(x, wpacked, y, B, Ci, Co, D, H, W, Do, Ho, Wo, st);
     return launch_deconv<1, 4>(x, wpacked, y, B, Ci, Co, D, H, W, Do, Ho, Wo, st);
+}
+
+// ---- 2-D: the data gradient of a stride-2 3x3 Conv2d (pad 1) = ConvTranspose2d(k 3, s 2, p 1) on a depth-1 volume ------
+extern "C" int ecm_deconv2d_pack_weight(const float* w, float* packed, int Ci, int Co, void* stream) {
+    ECM_CHECK_ARG(w && packed && Ci > 0 && Co > 0);
+    const int cop = ((Co + 31) / 32) * 32;
+    const int n = 9 * Ci * cop;
+    hipLaunchKernelGGL(pack_deconv_weight, dim3((n + 255) / 256), dim3(256), 0, ecm_stream(stream), w, packed, Ci, Co,
+                       cop, 9);
+    return ECM_LAUNCH_RESULT();
+}
+
+extern "C" int ecm_deconv2d_k3s2_fwd(const float* x, const float* wpacked, float* y, int B, int Ci, int Co, int H, int W,
+                                     int Ho, int Wo, void* stream) {
+    ECM_CHECK_ARG(x && wpacked && y && B > 0 && H > 0 && W > 0);
+    if (Ci % 4 != 0 || Co < 1 || Co > 64) return ECM_EUNSUP;
+    if (Ho > 2 * H || Ho < 2 * H - 1 || Wo > 2 * W || Wo < 2 * W - 1) return ECM_EUNSUP;
+    hipStream_t st = ecm_stream(stream);
+    if (Co > 32) return launch_deconv<2, 4, 1>(x, wpacked, y, B, Ci, Co, 1, H, W, 1, Ho, Wo, st);
+    return launch_deconv<1, 4, 1>(x, wpacked, y, B, Ci, Co, 1, H, W, 1, Ho, Wo, st);
 }

@@ -318,8 +318,8 @@ __device__ __forceinline__ bool slot_collect(const unsigned long long* slot, flo
 
 // Work assignment.  A cluster's `cl` workgroups must all be running for any of them to finish, so membership must not
 // depend on which workgroups the dispatcher happens to have placed: every workgroup draws TICKETS from one counter
-// (ticket t -> span t / cl, member t % cl).  All tickets below a drawn one are held by workgroups that are running (or
-// done), so at most ONE cluster is ever incomplete and every other running workgroup sits in a complete cluster, finishes
+// (ticket t -> span t / cl, member t % cl), and never waits while holding a ticket it has not published for.  All
+// tickets below a drawn one are then held by workgroups that are running towards their publish (or done), so at most ONE cluster is ever incomplete and every other running workgroup sits in a complete cluster, finishes
 // and draws the next ticket -- progress needs only `cl` running workgroups of this launch, whatever else shares the
 // device (a second stream or process, CU masks) and in whatever order the hardware dispatches.  The counter lives behind
 // the slots and is preset to 0xFFFFFFFF by the same memset (first draw wraps to 0).  STATIC = the round-1 scheme
@@ -425,13 +425,17 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         }
         block_reduce2(s, q, sm);
         unsigned long long* sp = ctl.slots + (size_t)span * cl;
-        unsigned tnext = 0;
-        if (tid == 0) { slot_publish(sp + wic, s, q); tnext = tk.next(t); }    // the draw's latency hides under the collect
+        if (tid == 0) slot_publish(sp + wic, s, q);
         // fixed-order total of the cl (<= 128) partials, identical in every workgroup of the cluster
         double ds = 0.0, dq = 0.0;
         int got = 1;
         if (tid < cl) { float ps, pq; got = slot_collect(sp + tid, ps, pq, ctl.poll_ticks) ? 1 : 0; ds = (double)ps; dq = (double)pq; }
         const bool arrived = __syncthreads_and(got) != 0;
+        // Draw the next ticket only now: a workgroup must never WAIT while it holds a ticket it has not published for
+        // (the drawn ticket could belong to the very cluster it waits on).  From here on nothing blocks, and the draw's
+        // latency hides under the finishing pass.
+        unsigned tnext = 0;
+        if (tid == 0) tnext = tk.next(t);
         ds = wave_sum_d(ds); dq = wave_sum_d(dq);
         if (lane == 0) { smd[wave * 2] = ds; smd[wave * 2 + 1] = dq; }
         __syncthreads();
@@ -539,8 +543,7 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
         }
         block_reduce2(sg, sgx, sm);
         unsigned long long* sp = ctl.slots + (size_t)span * cl;
-        unsigned tnext = 0;
-        if (tid == 0) { slot_publish(sp + wic, sg, sgx); tnext = tk.next(t); }
+        if (tid == 0) slot_publish(sp + wic, sg, sgx);
         // per-channel totals (fixed order): wave k reduces the wpc partials of channels k, k+4, ...
         int got = 1;
         for (int cc = wave; cc < cpg; cc += THREADS / 64) {
@@ -554,6 +557,8 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
             if (lane == 0) { chs[cc * 2] = ds; chs[cc * 2 + 1] = dq; }
         }
         const bool arrived = __syncthreads_and(got) != 0;
+        unsigned tnext = 0;
+        if (tid == 0) tnext = tk.next(t);             // only after the wait (see gn_fused_fwd)
         if (!arrived && tid == 0) report_timeout(ctl.status);
         float s1 = 0.f, s2 = 0.f;
         for (int j = 0; j < cpg; ++j) {

@@ -3,8 +3,8 @@
 Same class names, constructor signatures, attribute tree (=> identical `state_dict()` keys/shapes, so
 reference checkpoints load), same `forward` signatures and return shapes as
 `cmf/models/cmfsm.py` -- but every hot-path stage (cost volume, 3-D aggregation, soft-argmin, ECM
-weights, ECM aggregation) runs on the gfx950 kernels in `ops.py`.  The 2-D encoder stays on
-PyTorch-ROCm (MIOpen), as BASELINE.json's north_star prescribes.
+weights, ECM aggregation) runs on the gfx950 kernels in `ops.py`, and so do the 2-D encoder's convolutions and
+GroupNorms; PyTorch-ROCm supplies the pooling / interpolation / concatenation glue around them.
 
 Deliberate deviations (documented in DESIGN.md):
   * device-agnostic construction (no `.cuda()` inside modules, cf. cmfsm.py:98,117,427,671);
@@ -61,25 +61,27 @@ class HipReLU(nn.ReLU):
 
 
 class EncConv2d(nn.Conv2d):
-    """nn.Conv2d of the encoder.  The 3x3, stride-1, undilated layers with 32 or 64 channels on both sides run on the
-    MFMA kernels (forward, data gradient and weight gradient: ops.Conv2dK3); every other layer -- the 3-channel stem, the
-    stride-2 and dilated layers, the 128-channel stages, 1x1 convolutions -- stays on PyTorch-ROCm (MIOpen)."""
+    """nn.Conv2d of the encoder (same parameters, hence the reference's state_dict keys).  Every layer shape of the
+    registered architectures -- 3x3 with stride 1|2 and dilation 1|2|4, the 3-channel stem, the 64/128/320/384-channel
+    stages, the 1x1 projections -- runs on the MFMA implicit-GEMM family (ops.conv2d: forward, data and weight gradient);
+    a configuration outside it (none in the registered models) would fall to PyTorch-ROCm."""
 
-    def _hip_wgrad(self):
-        return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation == (1, 1)
-                and self.padding == (1, 1) and self.groups == 1 and self.bias is None
-                and self.in_channels in (32, 64) and self.out_channels in (32, 64))
+    def _native(self):
+        kh, kw = self.kernel_size
+        s, d = self.stride[0], self.dilation[0]
+        return (self.groups == 1 and self.bias is None and self.stride[0] == self.stride[1]
+                and self.dilation[0] == self.dilation[1] and self.padding == (d * (kh - 1) // 2, d * (kw - 1) // 2)
+                and self.padding_mode == "zeros" and ops.conv2d_supported(self.in_channels, self.out_channels, kh, kw, s, d))
 
     def forward(self, x):
-        if self._hip_wgrad():
-            return ops.conv2d_k3(x, self.weight)          # raises on CPU tensors, like every op of the package
+        if self._native():
+            return ops.conv2d(x, self.weight, self.stride[0], self.dilation[0])      # raises on CPU tensors, like every op
         return super().forward(x)
 
 
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
-    """2-D conv + GroupNorm of the encoder (cmfsm.py:36-46).  The convolution stays on PyTorch-ROCm (MIOpen) except for
-    the weight gradient of its 32/64-channel 3x3 layers; the GroupNorm (and the ReLU / residual add that follows it)
-    runs on the same fused HIP kernel as the 3-D stack."""
+    """2-D conv + GroupNorm of the encoder (cmfsm.py:36-46): the convolution on the MFMA 2-D family (EncConv2d), the
+    GroupNorm (and the ReLU / residual add that follows it) on the same fused HIP kernel as the 3-D stack."""
     return nn.Sequential(
         EncConv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
                   padding=dilation if dilation > 1 else pad, dilation=dilation, bias=False),
@@ -138,7 +140,7 @@ def _cbn(seq, x, skip=None, relu=False):
 
 
 # ------------------------------------------------------------------------------------------------
-# encoder (cmfsm.py:61-85, 126-236) -- plain PyTorch
+# encoder (cmfsm.py:61-85, 126-236)
 # ------------------------------------------------------------------------------------------------
 class BasicBlock(nn.Module):
     expansion = 1
@@ -249,7 +251,7 @@ class feature_extraction(nn.Module):
                 nn.AvgPool2d((pool, pool), stride=(pool, pool)), convbn(128, 32, 1, 1, 0, 1), nn.ReLU(inplace=True)))
         last = nn.Sequential(
             convbn(320 if cfg["raw"] == "layer2" else 384, 128, 3, 1, 1, 1), nn.ReLU(inplace=True),
-            nn.Conv2d(128, 32, kernel_size=1, padding=0, stride=1, bias=False))
+            EncConv2d(128, 32, kernel_size=1, padding=0, stride=1, bias=False))
         setattr(self, "lastconv" if cfg["raw"] == "layer2" else "lastconv_16", last)
         self._raw_is_layer3 = cfg["raw"] == "layer3"
 
@@ -257,7 +259,7 @@ class feature_extraction(nn.Module):
         downsample = None
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                EncConv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
                 HipGroupNorm(NUM_GROUPS, planes * block.expansion))
         layers = [block(self.inplanes, planes, stride, downsample, pad, dilation)]
         self.inplanes = planes * block.expansion

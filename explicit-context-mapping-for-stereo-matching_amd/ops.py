@@ -147,8 +147,11 @@ def costvol_conv3d(left, right, weight, ndisp):
     mP, mQ = _class_tap_masks(weight.device)
     wP = torch.einsum("xdk,oidhk->xoihk", mP, weight[:, :Cc]).reshape(15 * Co, Cc, 3, 3)
     wQ = torch.einsum("xdkq,oidhk->xoihq", mQ, weight[:, Cc:]).reshape(6 * Co, Cc, 3, 5)
-    P = conv2d_k3(left, wP) if Cc % 32 == 0 else torch.nn.functional.conv2d(left, wP, None, 1, 1)      # [B,15Co,h,w]
-    Qp = torch.nn.functional.conv2d(torch.nn.functional.pad(right, (2, 0)), wQ, None, 1, (1, 2))        # [B,6Co,h,w+2]
+    h, w = left.shape[-2:]
+    P = conv2d(left, wP, 1, 1, 1, 1, h, w)                      # 3x3, pad 1                                  [B,15Co,h,w]
+    # sheared 3x5 on the target features with 2 extra zero columns on the left: pad (1, 2) of F.pad(right, (2, 0)) is a
+    # left padding of 4 and a right padding of 2 -> output width w + 2                                        [B,6Co,h,w+2]
+    Qp = conv2d(right, wQ, 1, 1, 1, 4, h, w + 2)
     return CostvolConvAssemble.apply(P, Qp, int(ndisp))
 
 
@@ -488,67 +491,141 @@ def _dgrad_small_co(gy, w):
     return _conv_fwd(gyp, _pack_conv(wp, True), Ci, 1)
 
 
-def _pack_conv2d(w, flip_transpose=False):
-    Co, Ci = w.shape[:2]
-    kin, kout = (Co, Ci) if flip_transpose else (Ci, Co)
-    packed = torch.empty(_lib.query("ecm_conv2d_packed_floats", kin, kout), device=w.device, dtype=w.dtype)
-    _lib.call("ecm_conv2d_pack_weight", _p(_c(w)), _p(packed), Co, Ci, int(flip_transpose), _stream())
+# Packed-weight cache: one entry per (weight storage, layout); re-packed only when the tensor's version counter moves (an
+# optimizer step, load_state_dict).  In training every weight changes every step, so this costs nothing there; in eval /
+# no_grad loops it removes ~60 pack launches per forward.
+_PACKED = {}
+
+
+def _cached_pack(w, kind, build):
+    key = (w.data_ptr(), kind, tuple(w.shape))
+    hit = _PACKED.get(key)
+    ver = w._version
+    if hit is not None and hit[0] == ver and hit[1].device == w.device:
+        return hit[1]
+    if len(_PACKED) > 4096:
+        _PACKED.clear()
+    packed = build()
+    _PACKED[key] = (ver, packed)
     return packed
 
 
-def _conv2d_fwd(x, packed, Co):
+# (kh, kw, stride, dil) -> output-channel tilings (tiles of 32 per workgroup) the kernels are instantiated for; mirrors the
+# COTS masks of csrc/conv2d_case_*.hip and the tiling rule c2_plan() of csrc/conv2d_kernel.h
+_C2_CASES = {(3, 3, 1, 1): {1, 2, 3, 4}, (3, 3, 1, 2): {2, 4}, (3, 3, 1, 4): {4}, (3, 3, 2, 1): {1, 2, 4},
+             (3, 5, 1, 1): {1, 3}, (1, 1, 1, 1): {1, 2, 4}, (1, 1, 2, 1): {1, 2, 4}}
+
+
+def _cot(Co, kh, kw):
+    if Co <= 32:
+        return 1
+    if Co <= 64:
+        return 2
+    return 3 if (kh * kw != 1 and Co % 96 == 0 and Co % 128 != 0) else 4
+
+
+def conv2d_supported(Ci, Co, kh, kw, stride, dil):
+    """Is this layer -- forward AND data gradient -- inside the native 2-D family (csrc/conv2d.hip)?"""
+    cots = _C2_CASES.get((kh, kw, stride, dil))
+    if cots is None or _cot(Co, kh, kw) not in cots:
+        return False
+    if stride == 1:
+        return _cot(Ci, kh, kw) in cots                      # data gradient: same case with Cout' = Ci
+    if kh == 3:                                              # stride-2 3x3: transposed-conv kernel, <= 64 output channels
+        return Ci <= 64 and Co % 4 == 0
+    return _cot(Ci, 1, 1) in _C2_CASES[(1, 1, 1, 1)]         # stride-2 1x1: a stride-1 1x1 on the coarse grid + zero insertion
+
+
+def _pack2d(w, flip_transpose):
+    w = _c(w)
+    Co, Ci, kh, kw = w.shape
+    kin, kout = (Co, Ci) if flip_transpose else (Ci, Co)
+
+    def build():
+        packed = torch.empty(_lib.query("ecm_conv2d_packed_floats_ex", kin, kout, kh, kw), device=w.device, dtype=w.dtype)
+        _lib.call("ecm_conv2d_pack_weight_ex", _p(w), _p(packed), Co, Ci, kh, kw, int(flip_transpose), _stream())
+        return packed
+    return _cached_pack(w, "c2T" if flip_transpose else "c2", build)
+
+
+def _conv2d_run(x, packed, Co, kh, kw, stride, dil, pad_top, pad_left, Ho, Wo):
     B, Ci, H, W = x.shape
-    y = torch.empty(B, Co, H, W, device=x.device, dtype=x.dtype)
-    _lib.call("ecm_conv2d_k3_fwd", _p(x), _p(packed), _p(y), B, Ci, Co, H, W, _stream())
+    y = torch.empty(B, Co, Ho, Wo, device=x.device, dtype=x.dtype)
+    _lib.call("ecm_conv2d_fwd_ex", _p(x), _p(packed), _p(y), B, Ci, Co, H, W, kh, kw, stride, dil, pad_top, pad_left, Ho, Wo,
+              _stream())
     return y
 
 
-def _conv2d_native(w):
-    """Layers whose forward / data gradient run on the MFMA kernel: 32 or 64 channels on both sides, where it is level with
-    or ahead of MIOpen's Winograd (8 images: 32->32 at 576x960 0.75 / 0.72 ms vs 0.82 / 0.84 ms; 64->64 at 144x240 0.186 ms
-    vs 0.200 ms; tools/miopen_conv2d_probe.py).  Wider layers, the 3-channel stem and the class convolutions of
-    costvol_conv3d stay on MIOpen."""
-    return w.shape[0] in (32, 64) and w.shape[1] in (32, 64)
-
-
-class Conv2dK3(torch.autograd.Function):
-    """The encoder's 3x3 / stride 1 / pad 1 Conv2d (convbn, cmfsm.py:37-47).  Weight gradient: the MFMA wgrad kernel
-    (depth-1 volume, 9 taps), where MIOpen's fp32 kernels reach 45-77 TFLOP/s.  Forward and data gradient: the MFMA
-    implicit-GEMM kernel for the 32/64-channel layers (see _conv2d_native), MIOpen otherwise (e.g. the 15*32-channel class
-    convolution of costvol_conv3d)."""
+class Conv2dG(torch.autograd.Function):
+    """nn.Conv2d(bias=False) of the encoder (convbn, cmfsm.py:36-46; 1x1 projections 152-170, 231-236) and the class
+    convolutions of the collapsed cost volume, on the MFMA implicit-GEMM kernels: forward, data gradient (stride 1: the
+    same kernel on flipped / transposed weights; stride 2: the transposed-conv kernel) and weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, stride, dil, pad_top, pad_left, Ho, Wo):
         _chk(x, w)
+        x = _c(x)
+        Co, Ci, kh, kw = w.shape
+        y = _conv2d_run(x, _pack2d(w, False), Co, kh, kw, stride, dil, pad_top, pad_left, Ho, Wo)
         ctx.save_for_backward(x, w)
-        if _conv2d_native(w):
-            return _conv2d_fwd(_c(x), _pack_conv2d(w), w.shape[0])
-        return torch.nn.functional.conv2d(x, w, None, 1, 1, 1)
+        ctx.cfg = (stride, dil, pad_top, pad_left, Ho, Wo)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
+        stride, dil, pad_top, pad_left, Ho, Wo = ctx.cfg
+        Co, Ci, kh, kw = w.shape
+        B, _, H, W = x.shape
+        gy = _c(gy)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            if _conv2d_native(w):
-                gx = _conv2d_fwd(_c(gy), _pack_conv2d(w, True), w.shape[1])
+            if stride == 1:
+                # gx[i] = sum_k w[k] gy[i + pad - k*dil]: the conv of gy with the flipped kernel, padding (K-1)*dil - pad
+                gx = _conv2d_run(gy, _pack2d(w, True), Ci, kh, kw, 1, dil, (kh - 1) * dil - pad_top, (kw - 1) * dil - pad_left,
+                                 H, W)
+            elif kh == 3:
+                if pad_top != 1 or pad_left != 1:
+                    raise RuntimeError("stride-2 3x3 data gradient: padding 1 only")
+                wc = _c(w)
+
+                def build():
+                    packed = torch.empty(9 * Co * ((Ci + 31) // 32) * 32, device=w.device, dtype=w.dtype)
+                    _lib.call("ecm_deconv2d_pack_weight", _p(wc), _p(packed), Co, Ci, _stream())
+                    return packed
+                gx = torch.empty(B, Ci, H, W, device=x.device, dtype=x.dtype)
+                _lib.call("ecm_deconv2d_k3s2_fwd", _p(gy), _p(_cached_pack(wc, "d2", build)), _p(gx), B, Co, Ci, Ho, Wo, H, W,
+                          _stream())
             else:
-                gx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
-                                                         (True, False, False))[0]
+                # 1x1, stride 2 (the downsample projections): W^T gy lands on the even positions, zeros elsewhere
+                small = _conv2d_run(gy, _pack2d(w, True), Ci, 1, 1, 1, 1, 0, 0, Ho, Wo)
+                gx = torch.zeros(B, Ci, H, W, device=x.device, dtype=x.dtype)
+                gx[:, :, ::2, ::2] = small
         if ctx.needs_input_grad[1]:
-            xc, gc = _c(x), _c(gy)
-            B, Ci, H, W = xc.shape
-            Co = w.shape[0]
             gw = _empty_like(w)
-            nb = _lib.query("ecm_conv2d_k3_wgrad_scratch_bytes", B, Ci, Co, H, W)
+            nb = _lib.query("ecm_conv2d_wgrad_ex_scratch_bytes", B, Ci, Co, Ho, Wo, kh, kw, stride)
             scratch = _scratch(nb, x.device)
-            _lib.call("ecm_conv2d_k3_wgrad", _p(xc), _p(gc), _p(gw), _p(scratch), C.c_longlong(nb), B, Ci, Co, H, W,
-                      _stream())
-        return gx, gw
+            _lib.call("ecm_conv2d_wgrad_ex", _p(x), _p(gy), _p(gw), _p(scratch), C.c_longlong(nb), B, Ci, Co, H, W, kh, kw,
+                      stride, dil, pad_top, pad_left, Ho, Wo, _stream())
+        return gx, gw, None, None, None, None, None, None
+
+
+def conv2d(x, w, stride=1, dil=1, pad_top=None, pad_left=None, Ho=None, Wo=None):
+    """General native 2-D convolution; default padding "same-style" dil*(k-1)/2 and the matching output size."""
+    kh, kw = w.shape[-2:]
+    H, W = x.shape[-2:]
+    pt = dil * (kh - 1) // 2 if pad_top is None else int(pad_top)
+    pl = dil * (kw - 1) // 2 if pad_left is None else int(pad_left)
+    if Ho is None:
+        Ho = (H + 2 * pt - dil * (kh - 1) - 1) // stride + 1
+    if Wo is None:
+        Wo = (W + 2 * pl - dil * (kw - 1) - 1) // stride + 1
+    return Conv2dG.apply(x, w, int(stride), int(dil), pt, pl, int(Ho), int(Wo))
 
 
 def conv2d_k3(x, w):
-    return Conv2dK3.apply(x, w)
+    """3x3 / stride 1 / pad 1 (kept as the name the 32/64-channel encoder layers were introduced under)."""
+    return conv2d(x, w, 1, 1)
 
 
 def conv3d_k3(x, w, stride=1):

@@ -163,6 +163,31 @@ long long ecm_conv2d_k3_wgrad_scratch_bytes(int B, int Ci, int Co, int H, int W)
 int ecm_conv2d_k3_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
                         int B, int Ci, int Co, int H, int W, void* stream);
 
+/* General 2-D convolution family (conv2d.hip), same implicit-GEMM kernel: the encoder's Conv2d layers (feature_extraction,
+ * cmfsm.py:126-236: 3x3 with stride 1|2 and dilation 1|2|4, the 3-channel stem, 64/128/320-channel stages, 1x1 projections),
+ * the class-indexed convolutions of the collapsed cost volume (3x3 32->480, sheared 3x5 32->192; cmfsm.py:667-684) and all
+ * stride-1 data gradients (flip_transpose packing).  (kh,kw,stride,dil) in {(3,3,1,1|2|4), (3,3,2,1), (3,5,1,1), (1,1,1|2,1)}.
+ *   y[b,co,oh,ow] = sum w[co,ci,i,j] x[b,ci,oh*stride - pad_top + i*dil, ow*stride - pad_left + j*dil]   (0 outside x)
+ * x: [B,Ci,H,W]; y: [B,Co,Ho,Wo] -- Ho, Wo and the top/left padding are given explicitly (the bottom/right padding is
+ * whatever Ho, Wo imply), which also covers asymmetric padding.  packed: ecm_conv2d_packed_floats_ex floats, filled by
+ * ecm_conv2d_pack_weight_ex from the reference layout [Co,Ci,kh,kw] (flip_transpose: the data-gradient operator with
+ * Cin' = Co, Cout' = Ci; call the size query with the swapped channel counts). */
+long long ecm_conv2d_packed_floats_ex(int Ci, int Co, int kh, int kw);
+int ecm_conv2d_pack_weight_ex(const float* w, float* packed, int Co, int Ci, int kh, int kw, int flip_transpose, void* stream);
+int ecm_conv2d_fwd_ex(const float* x, const float* wpacked, float* y, int B, int Ci, int Co, int H, int W, int kh, int kw,
+                      int stride, int dil, int pad_top, int pad_left, int Ho, int Wo, void* stream);
+/* gw[co,ci,kh,kw] = sum_{b,oh,ow} gy[b,co,oh,ow] x[b,ci,oh*stride - pad_top + i*dil, ow*stride - pad_left + j*dil] for the
+ * same family; gy: [B,Co,Ho,Wo].  Deterministic (per-workgroup partials, fixed-order sum). */
+long long ecm_conv2d_wgrad_ex_scratch_bytes(int B, int Ci, int Co, int Ho, int Wo, int kh, int kw, int stride);
+int ecm_conv2d_wgrad_ex(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B, int Ci,
+                        int Co, int H, int W, int kh, int kw, int stride, int dil, int pad_top, int pad_left, int Ho, int Wo,
+                        void* stream);
+/* Data gradient of a stride-2 3x3 Conv2d (pad 1) = ConvTranspose2d(k 3, stride 2, pad 1): x [B,Ci,H,W] -> y [B,Co,Ho,Wo],
+ * Ho in {2H-1, 2H}.  w: a Conv2d weight [Co_f = Ci here, Ci_f = Co here, 3, 3] as it stands.  Co <= 64, Ci % 4 == 0. */
+int ecm_deconv2d_pack_weight(const float* w, float* packed, int Ci, int Co, void* stream);
+int ecm_deconv2d_k3s2_fwd(const float* x, const float* wpacked, float* y, int B, int Ci, int Co, int H, int W, int Ho, int Wo,
+                          void* stream);
+
 /* GroupNorm(32 groups, eps) over [B,C,S] (S = D*H*W), cmfsm.py:58; deterministic fixed-order reductions.
  * scratch for every call: >= ecm_gn3d_scratch_bytes(B,C,S).
  * fwd: y = relu?( (x-mean)*rstd*gamma[c]+beta[c] (+ skip) ) (skip may be NULL) and mean_rstd [B,32,2] in ONE pass over x

@@ -27,11 +27,22 @@ def gen(seed):
     return torch.Generator(device="cuda").manual_seed(seed)
 
 
-def rel_close(a, b, tol, what=""):
-    """max |a - b| <= tol * max |b| (a whole-tensor bound: gradients span many orders of magnitude)."""
-    err = float((a - b).abs().max())
+def rel_close(a, b, tol, what="", kinks=0, kink_tol=0.1):
+    """max |a - b| <= tol * max |b| (a whole-tensor bound: gradients span many orders of magnitude).
+    `kinks`: number of elements allowed to miss `tol` (but not kink_tol * max |b|).  A ReLU / LeakyReLU whose pre-activation
+    is within an ulp or two of zero can take the other branch when the same sum is formed in a different order; among
+    10^8..10^9 activations that happens a few dozen times, and each flip changes ONE term of the affected gradient sums by
+    up to 99 % of that term -- a property of comparing two fp32 evaluation orders at this size, not of either one."""
+    a, b = a.detach(), b.detach()
+    d = (a - b).abs()
     ref = float(b.abs().max())
-    assert err <= tol * ref + 1e-30, f"{what}: max err {err:.3e} vs max |ref| {ref:.3e} (tol {tol})"
+    err = float(d.max())
+    if kinks == 0:
+        assert err <= tol * ref + 1e-30, f"{what}: max err {err:.3e} vs max |ref| {ref:.3e} (tol {tol})"
+        return
+    n_out = int((d > tol * ref).sum())
+    assert n_out <= kinks and err <= kink_tol * ref, \
+        f"{what}: {n_out} elements beyond {tol} * max |ref| (allowed {kinks}), max err {err:.3e} vs max |ref| {ref:.3e}"
 
 
 # ---------------------------------------------------------------------------------------------- (a) cfg 5 cost volume
@@ -107,8 +118,19 @@ def test_groupnorm_fwd_bwd_production_size(ecm, shape, relu, skip):
     torch.testing.assert_close(y, ref, rtol=1e-4, atol=2e-5)
     y.backward(G)
     ref.backward(G)
+    gx, gx_ref = got_in[0].grad, ref_in[0].grad
+    if relu:
+        # where the pre-activation is within rounding of 0 the two evaluations may take different ReLU branches (1-3 of
+        # 2e8 elements at this size): those positions are excluded from the comparison, everything else must agree
+        tie = ref.detach() <= 2e-5
+        tie &= y.detach() <= 2e-5
+        pre_small = tie & ((y.detach() > 0) != (ref.detach() > 0))
+        assert int(pre_small.sum()) <= 16
+        gx, gx_ref = torch.where(pre_small, gx_ref, gx), gx_ref
+        if skip:
+            got_in[3].grad = torch.where(pre_small, ref_in[3].grad, got_in[3].grad)
     del y, ref
-    torch.testing.assert_close(got_in[0].grad, ref_in[0].grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(gx, gx_ref, rtol=1e-3, atol=1e-4)
     rel_close(got_in[1].grad, ref_in[1].grad, 1e-3, "ggamma")
     rel_close(got_in[2].grad, ref_in[2].grad, 1e-3, "gbeta")
     if skip:
@@ -160,7 +182,10 @@ def test_ecm_weights9_restatement_matches_kernel_small(ecm):
 
 def test_ecm_weights9_backward_576x960(ecm):
     """ecm_weights9 forward + backward at 576x960 (batch 2) vs autograd of the closed form: glr, ghr and the four MLP
-    weight gradients (sums over 1.1 M pixels x 9 neighbours)."""
+    weight gradients (sums over 1.1 M pixels x 9 neighbours).  The MLP has ~3e8 LeakyReLU units per pass; a few hundred sit
+    within rounding of their kink, where two fp32 evaluation orders pick different slopes and ONE term of a gradient sum
+    changes by 99 %.  So the yardstick is the fp64 evaluation of the same closed form: the kernel must be as close to it as
+    torch's own fp32 evaluation is (same bulk tolerance, comparable number and size of kink outliers)."""
     B, h, w = 2, 144, 240
     lr = torch.randn(B, 32, h, w, device="cuda", generator=gen(51))
     hr = torch.randn(B, 32, 4 * h, 4 * w, device="cuda", generator=gen(52))
@@ -175,10 +200,26 @@ def test_ecm_weights9_backward_576x960(ecm):
     w9.backward(G)
     ref.backward(G)
     del w9, ref
-    rel_close(a[0].grad, b[0].grad, 1e-4, "glr")
-    rel_close(a[1].grad, b[1].grad, 1e-4, "ghr")
-    for i, nm in enumerate(("gW0", "gW1", "gW2", "gW3")):
-        rel_close(a[2 + i].grad, b[2 + i].grad, 5e-4, nm)
+    grads64 = []
+    for bi in range(B):                                  # fp64 truth, one sample at a time (memory)
+        c = [t[bi:bi + 1].double().requires_grad_() for t in (lr, hr)] + [t.double().requires_grad_() for t in Ws]
+        ecm_weights9_torch(*c).backward(G[bi:bi + 1].double())
+        grads64.append([t.grad for t in c])
+    truth = [torch.cat([g[0] for g in grads64]), torch.cat([g[1] for g in grads64])] + \
+            [sum(g[2 + i] for g in grads64) for i in range(4)]
+    for i, nm in enumerate(("glr", "ghr", "gW0", "gW1", "gW2", "gW3")):
+        t64 = truth[i]
+        scale = float(t64.abs().max())
+        e_hip = (a[i].grad.double() - t64).abs()
+        e_t32 = (b[i].grad.double() - t64).abs()
+        tol = (1e-4 if i < 2 else 5e-4) * scale
+        n_hip, n_t32 = int((e_hip > tol).sum()), int((e_t32 > tol).sum())
+        assert n_hip <= 3 * n_t32 + 64, f"{nm}: {n_hip} elements beyond tolerance vs {n_t32} for torch fp32"
+        assert float(e_hip.max()) <= 3.0 * float(e_t32.max()) + tol, \
+            f"{nm}: max error {float(e_hip.max()):.3e} vs torch fp32's {float(e_t32.max()):.3e} (scale {scale:.3e})"
+        # the bulk: 99.99 % of the elements within the plain fp32 tolerance
+        if e_hip.numel() > 100000:
+            assert float(torch.quantile(e_hip.flatten()[:8000000].float(), 0.9999)) <= tol, nm
 
 
 def test_heads_backward_576x960(ecm):

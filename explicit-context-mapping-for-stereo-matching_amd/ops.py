@@ -491,22 +491,25 @@ def _dgrad_small_co(gy, w):
     return _conv_fwd(gyp, _pack_conv(wp, True), Ci, 1)
 
 
-# Packed-weight cache: one entry per (weight storage, layout); re-packed only when the tensor's version counter moves (an
-# optimizer step, load_state_dict).  In training every weight changes every step, so this costs nothing there; in eval /
-# no_grad loops it removes ~60 pack launches per forward.
-_PACKED = {}
-
-
+# Packed-weight cache: the packed layouts ride on the weight tensor OBJECT (an attribute), tagged with its version counter
+# and storage address, so a parameter is re-packed only after an optimizer step / load_state_dict / device move.  In training
+# every weight changes every step, so this saves nothing there; in eval / no_grad loops it removes ~60 pack launches per
+# forward.  Temporaries (e.g. the class kernels of costvol_conv3d) die with their cache.  (Keying a global table by
+# data_ptr would be wrong: the caching allocator hands the same address to the next tensor of that size.)
 def _cached_pack(w, kind, build):
-    key = (w.data_ptr(), kind, tuple(w.shape))
-    hit = _PACKED.get(key)
-    ver = w._version
-    if hit is not None and hit[0] == ver and hit[1].device == w.device:
+    cache = getattr(w, "_ecm_packed", None)
+    if cache is None:
+        cache = {}
+        try:
+            w._ecm_packed = cache
+        except AttributeError:
+            return build()
+    tag = (w._version, w.data_ptr(), w.device)
+    hit = cache.get(kind)
+    if hit is not None and hit[0] == tag:
         return hit[1]
-    if len(_PACKED) > 4096:
-        _PACKED.clear()
     packed = build()
-    _PACKED[key] = (ver, packed)
+    cache[kind] = (tag, packed)
     return packed
 
 

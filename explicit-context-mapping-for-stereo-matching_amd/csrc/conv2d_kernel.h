@@ -13,6 +13,7 @@
 // channel counts that are not a multiple of the chunk (the 3-channel stem) read zeros for the missing planes.
 #pragma once
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -209,9 +210,13 @@ int launch_c2(const float* x, const float* wp, float* y, int B, int Ci, int CiP,
 }
 
 // rows per wave: the largest tile that still gives the chip >= ~3 rounds of workgroups
+inline int c2_min_blocks() {
+    static const int v = [] { const char* e = getenv("ECM_C2_MIN_BLOCKS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 1536; }();
+    return v;
+}
 inline int c2_nt(long long cols_x_groups, int Ho, int max_nt) {
     for (int nt = max_nt; nt > 1; nt >>= 1)
-        if (cols_x_groups * ((Ho + 4 * nt - 1) / (4 * nt)) >= 1536) return nt;
+        if (cols_x_groups * ((Ho + 4 * nt - 1) / (4 * nt)) >= c2_min_blocks()) return nt;
     return 1;
 }
 

@@ -1,0 +1,350 @@
+// Stride-1 3x3x3 Conv3d / 3x3 Conv2d (pad 1, no bias) by Winograd F(2x2, 3x3) in the (h, w) plane -- direct along depth --
+// on the fp32 matrix cores.  Reference ops: nn.Conv3d inside convbn_3d (cmfsm.py:49-58; dres0/1 604-613, hourglass
+// 244-259, classif 621-634) and the encoder's 3x3 convbn layers (cmfsm.py:36-46); with flipped / transposed weights the
+// same kernel is their data gradient.
+//
+// For a 2x2 output tile, Y = A^T [ sum_{kd,ci} U[kd,co,ci] (.) V[ci,d+kd-1] ] A with U = G g G^T (4x4 per filter plane) and
+// V = B^T x B (4x4 per input patch): 16 multiplies per 4 outputs per (kd,ci,co) instead of 36 -- 2.25x fewer MFMAs than
+// the implicit GEMM of conv3d.hip, all in fp32 (v_mfma_f32_32x32x2_f32; the transforms only add / subtract and halve).
+//
+// GEMM per frequency xi in [0,16):  M_xi[co][p][r][t] += sum_{kd,ci} U_xi[kd][ci][co] * V_xi[ci][p+kd][r][t]
+//   A = U_xi : lane l holds U[k = l>>5][co = l&31]            (LDS image [xi][kd][ci][co], global->LDS DMA, double buffered)
+//   B = V_xi : lane l holds V[k = l>>5][tile column t = l&31] (LDS image [xi][ci][plane][tile row][32], double buffered)
+// One workgroup (4 waves) owns TD planes x TR tile rows x 32 tile columns of 2x2 tiles (TD x 2TR x 64 outputs) for 32
+// output channels; wave w owns the frequencies 4w..4w+3 (4 x TD*TR accumulators of 16 registers).  Per chunk of CIC input
+// channels every thread transforms ONE 4x4 input patch (16 buffer loads with hardware zero padding -> 32 adds -> 16 LDS
+// stores), prefetched one chunk ahead through registers, while the previous chunk's MFMAs run; one barrier per chunk; two
+// workgroups per CU so that one's transform / barrier sits under the other's matrix work.  Epilogue: the column half of
+// A^T M A in registers (a wave owns one frequency row), the row half after an exchange through LDS.
+#include "common.h"
+
+#ifdef WINO_PROFILE
+__device__ unsigned long long wino_prof[4 * 8];   // [wave][phase] cycles of one workgroup; debugging aid (tools/micro/wino_prof.hip)
+#define WN_T(i) do { const unsigned long long now_ = clock64(); prof[i] += now_ - last; last = now_; } while (0)
+#else
+#define WN_T(i) do { } while (0)
+#endif
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KD, int TD, int TR, int CIC>
+struct WinoCfg {
+    static constexpr int NP = TD + KD - 1;                 // input planes per tile
+    static constexpr int NPR = TD * TR;                    // (plane, tile row) pairs = accumulators per frequency
+    static constexpr int V_FLOATS = 16 * CIC * NP * TR * 32;
+    static constexpr int U_FLOATS = 16 * KD * CIC * 32;
+    static constexpr int LDS_FLOATS = 2 * (V_FLOATS + U_FLOATS);
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static_assert(CIC * NP * TR * 32 == 256, "one input patch per thread per chunk");
+    static_assert(CIC % 2 == 0 && (256 / (NP * TR * 32)) == CIC, "channel of a patch must be wave-uniform");
+    static_assert(4 * 2 * 32 * 32 <= LDS_FLOATS, "epilogue exchange buffer must fit");
+};
+
+// packed weights: [co group][chunk][xi][kd][cc][32 co]  (chunk = CIC input channels; zero rows / columns beyond Ci / Co)
+template <int KD, int TD, int TR, int CIC>
+__global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict__ x, const float* __restrict__ up,
+                                                      float* __restrict__ y, int Ci, int nchunks, int Co, int D, int H,
+                                                      int W, int tiles_d, int tiles_h, int tiles_w) {
+    using Cfg = WinoCfg<KD, TD, TR, CIC>;
+    constexpr int NP = Cfg::NP, NPR = Cfg::NPR, VF = Cfg::V_FLOATS, UF = Cfg::U_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Vs = smem;                       // 2 x [16][CIC][NP][TR][32]
+    float* Us = smem + 2 * VF;              // 2 x [16][KD][CIC][32]
+
+    int bid = ecm_xcd_tile(blockIdx.x, gridDim.x);
+    const int td = bid % tiles_d; bid /= tiles_d;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h;
+    const int b = bid / tiles_h;
+    const int grp = blockIdx.y;
+    const int od0 = td * TD, oh0 = th * (2 * TR), ow0 = tw * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // ---- this thread's input patch: (channel-in-chunk pc, plane pz, tile row pr, tile column l31) ----------------------
+    const int rest = tid >> 5;                               // 0..7
+    const int pc = rest / (NP * TR);                         // wave-uniform (static_assert above)
+    const int pz = (rest / TR) % NP, pr = rest % TR;
+    const size_t HWi = (size_t)H * W, DHWi = (size_t)D * HWi;
+    unsigned poff[16];
+    {
+        const int gz = od0 - KD / 2 + pz;
+        const int gy0 = oh0 - 1 + 2 * pr, gx0 = ow0 - 1 + 2 * l31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gy = gy0 + i, gx = gx0 + j;
+                const bool ok = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                poff[i * 4 + j] = ok ? (unsigned)(gz * (int)HWi + gy * W + gx) * 4u : 0x80000000u;
+            }
+    }
+    const float* xb = x + (size_t)b * Ci * DHWi;
+    const unsigned plane_bytes = (unsigned)DHWi * 4u;
+    const int pc_u = __builtin_amdgcn_readfirstlane(pc);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const float* ug = up + (size_t)grp * nchunks * UF;
+
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    constexpr int NUQ = (UF / 4 + 255) / 256;                // weight float4s per thread per chunk
+    static_assert(UF % 4 == 0, "weight chunk moves as float4");
+
+    float raw[16];
+    auto load_raw = [&](int chunk) {
+        const int c = chunk * CIC + pc_u;
+        const bool live = c < Ci;                            // channel padding: an empty descriptor reads zeros
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(live ? c : 0) * DHWi), 0,
+                                                            live ? plane_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            raw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, poff[k], 0, 0));
+    };
+    auto dma_u = [&](int chunk, float* dst) {
+        const float* src = ug + (size_t)chunk * UF;
+#pragma unroll
+        for (int i = 0; i < NUQ; ++i) {
+            const int e = tid + i * 256;
+            if (e < UF / 4)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)e * 4), (lds_ptr_t)(dst + (wave_u * 64 + i * 256) * 4), 16, 0, 0);
+        }
+    };
+    // V = B^T d B of the patch in `raw` -> Vs image `dst`: 16 frequency planes, this thread's (pc, pz, pr, t) slot.
+    // Two halves so that each fits into the shadow of one group of MFMAs in the main loop.
+    float tmp[16];
+    auto transform_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                        // rows: B^T d
+            const float d0 = raw[j], d1 = raw[4 + j], d2 = raw[8 + j], d3 = raw[12 + j];
+            tmp[j] = d0 - d2; tmp[4 + j] = d1 + d2; tmp[8 + j] = d2 - d1; tmp[12 + j] = d1 - d3;
+        }
+    };
+    auto transform_cols_store = [&](float* dst) {
+        float* vp = dst + ((pc * NP + pz) * TR + pr) * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                        // columns: (.) B
+            const float e0 = tmp[i * 4], e1 = tmp[i * 4 + 1], e2 = tmp[i * 4 + 2], e3 = tmp[i * 4 + 3];
+            vp[(i * 4 + 0) * (CIC * NP * TR * 32)] = e0 - e2;
+            vp[(i * 4 + 1) * (CIC * NP * TR * 32)] = e1 + e2;
+            vp[(i * 4 + 2) * (CIC * NP * TR * 32)] = e2 - e1;
+            vp[(i * 4 + 3) * (CIC * NP * TR * 32)] = e1 - e3;
+        }
+    };
+
+    f32x16 acc[4][NPR];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int q = 0; q < NPR; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[f][q][i] = 0.f;
+
+#ifdef WINO_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = clock64();
+#endif
+    // ---- prologue: chunk 0 into buffer 0, chunk 1's patch into registers -------------------------------------------------
+    dma_u(0, Us);
+    load_raw(0);
+    transform_rows();
+    transform_cols_store(Vs);
+    if (nchunks > 1) {
+        load_raw(1);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the weight DMA (older than the 16 patch loads) has landed
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    WN_T(0);
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        const float* Vc = Vs + buf * VF;
+        const float* Uc = Us + buf * UF;
+        float* Vn = Vs + (buf ^ 1) * VF;
+        // (1) every MFMA operand of this chunk into registers with ONE burst of LDS reads (left to itself hipcc reads two or
+        //     three operands at a time and waits lgkmcnt(0) in front of every small group of MFMAs: ~8 exposed LDS latencies
+        //     per 24 MFMAs)
+        float av[4][CIC / 2][KD], bw[4][CIC / 2][NP][TR];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int kk = 0; kk < CIC / 2; ++kk) {
+                const int xi = wave * 4 + f;
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int r = 0; r < TR; ++r)
+                        bw[f][kk][p][r] = Vc[(((xi * CIC + kk * 2 + half) * NP + p) * TR + r) * 32 + l31];
+#pragma unroll
+                for (int kd = 0; kd < KD; ++kd) av[f][kk][kd] = Uc[((xi * KD + kd) * CIC + kk * 2 + half) * 32 + l31];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        WN_T(1);
+        // (2) the MFMAs, one frequency (KD*CIC/2*NPR of them) at a time, each group followed by a slice of the staging work
+        //     for the chunks ahead, small enough to issue in the shadow of the group's last MFMA: the next chunk's patch
+        //     (loaded during the previous iteration) -> the other V buffer, next chunk's weights (DMA), the patch after it
+        //     -> registers.  sched_barriers pin that interleave.
+        const bool more = c + 1 < nchunks, more2 = c + 2 < nchunks;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+#pragma unroll
+            for (int kk = 0; kk < CIC / 2; ++kk)
+#pragma unroll
+                for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+                    for (int p = 0; p < TD; ++p)
+#pragma unroll
+                        for (int r = 0; r < TR; ++r)
+                            acc[f][p * TR + r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f][kk][kd], bw[f][kk][p + kd][r],
+                                                                                      acc[f][p * TR + r], 0, 0, 0);
+            if (f == 0 && more) transform_rows();
+            if (f == 1 && more) transform_cols_store(Vn);
+            if (f == 2 && more) dma_u(c + 1, Us + (buf ^ 1) * UF);
+            if (f == 3 && more2) load_raw(c + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        WN_T(2);
+        // weight DMA of chunk c+1 landed: it is older than the 16 patch loads of chunk c+2, the only younger VMEM operations
+        if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WN_T(3);
+        __syncthreads();
+        WN_T(4);
+    }
+
+    // ---- epilogue: Y = A^T M A.  Wave w owns frequency ROW i = w (xi = 4w + j), so the column half of the transform,
+    // T[i][b] = sum_j M[i][j] A[j][b], is done in registers; only T (2 of 4 values) crosses the waves through LDS:
+    // Ts[4 i][2 b][32 co][32 t] = 32 KB per (plane, tile row) pair q, then Y[a][b] = sum_i A^T[a][i] T[i][b].
+    float* Ts = smem;
+    const size_t HWo = HWi, DHWo = DHWi;                     // stride 1, pad 1: output volume == input volume
+    float* yb = y + (size_t)b * Co * DHWo;
+    const bool w_even = (W & 1) == 0;
+#pragma unroll
+    for (int q = 0; q < NPR; ++q) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = (i & 3) + 8 * (i >> 2) + 4 * half;
+            const float m0 = acc[0][q][i], m1 = acc[1][q][i], m2 = acc[2][q][i], m3 = acc[3][q][i];
+            Ts[((wave * 2 + 0) * 32 + co) * 32 + l31] = m0 + m1 + m2;
+            Ts[((wave * 2 + 1) * 32 + co) * 32 + l31] = m1 - m2 - m3;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {                     // 1024 (co, t) pairs per q: 4 per thread
+            const int e = tid + e4 * 256;
+            const int t = e & 31, col = e >> 5;
+            float tv[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq) tv[i][bq] = Ts[((i * 2 + bq) * 32 + col) * 32 + t];
+            const float y00 = tv[0][0] + tv[1][0] + tv[2][0], y01 = tv[0][1] + tv[1][1] + tv[2][1];
+            const float y10 = tv[1][0] - tv[2][0] - tv[3][0], y11 = tv[1][1] - tv[2][1] - tv[3][1];
+            const int co = grp * 32 + col;
+            const int od = od0 + q / TR, oh = oh0 + 2 * (q % TR), ow = ow0 + 2 * t;
+            if (co < Co && od < D && ow < W) {
+                float* yp = yb + (size_t)co * DHWo + (size_t)od * HWo + (size_t)oh * W + ow;
+                const bool two = ow + 1 < W;
+                if (oh < H) {
+                    if (two && w_even) *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
+                    else { yp[0] = y00; if (two) yp[1] = y01; }
+                }
+                if (oh + 1 < H) {
+                    if (two && w_even) *reinterpret_cast<float2*>(yp + W) = make_float2(y10, y11);
+                    else { yp[W] = y10; if (two) yp[W + 1] = y11; }
+                }
+            }
+        }
+        if (q + 1 < NPR) __syncthreads();
+    }
+#ifdef WINO_PROFILE
+    WN_T(5);
+    if (blockIdx.x == 2000 && blockIdx.y == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) wino_prof[wave * 8 + i] = prof[i];
+#endif
+}
+
+// w [Co][Ci][KD][3][3] (or, flip_transpose: the data-gradient operator w'[ci][co][flipped taps]) -> U = G g G^T,
+// packed [co group][chunk][xi][kd][cc][32]
+__global__ void pack_wino_weight(const float* __restrict__ w, float* __restrict__ packed, int Co, int Ci, int KD, int CIC,
+                                 int nchunks, int flip_transpose, long long n) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int Kin = flip_transpose ? Co : Ci, Kout = flip_transpose ? Ci : Co;
+    const int o = (int)(idx % 32);
+    long long r = idx / 32;
+    const int cc = (int)(r % CIC); r /= CIC;
+    const int kd = (int)(r % KD); r /= KD;
+    const int xi = (int)(r % 16); r /= 16;
+    const int chunk = (int)(r % nchunks);
+    const int grp = (int)(r / nchunks);
+    const int oc = grp * 32 + o, k = chunk * CIC + cc;
+    float v = 0.f;
+    if (oc < Kout && k < Kin) {
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bq = 0; bq < 3; ++bq) {
+                if (!flip_transpose) g[a][bq] = w[(((size_t)oc * Ci + k) * KD + kd) * 9 + a * 3 + bq];
+                else g[a][bq] = w[(((size_t)k * Ci + oc) * KD + (KD - 1 - kd)) * 9 + (2 - a) * 3 + (2 - bq)];
+            }
+        // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]];  U[i][j] = sum_ab G[i][a] g[a][b] G[j][b]
+        const int i = xi >> 2, j = xi & 3;
+        float row[3];                                        // (G g)[i][:]
+#pragma unroll
+        for (int bq = 0; bq < 3; ++bq)
+            row[bq] = i == 0 ? g[0][bq] : i == 3 ? g[2][bq] : i == 1 ? 0.5f * (g[0][bq] + g[1][bq] + g[2][bq])
+                                                                      : 0.5f * (g[0][bq] - g[1][bq] + g[2][bq]);
+        v = j == 0 ? row[0] : j == 3 ? row[2] : j == 1 ? 0.5f * (row[0] + row[1] + row[2]) : 0.5f * (row[0] - row[1] + row[2]);
+    }
+    packed[idx] = v;
+}
+
+template <int KD, int TD, int TR, int CIC>
+int launch_wino(const float* x, const float* up, float* y, int B, int Ci, int Co, int D, int H, int W, hipStream_t st) {
+    using Cfg = WinoCfg<KD, TD, TR, CIC>;
+    const int tiles_d = (D + TD - 1) / TD, tiles_h = (H + 2 * TR - 1) / (2 * TR), tiles_w = (W + 63) / 64;
+    const long long nblk = (long long)B * tiles_d * tiles_h * tiles_w;
+    const int groups = (Co + 31) / 32, nchunks = (Ci + CIC - 1) / CIC;
+    if (nblk > 0x7fffffffLL || groups > 65535 || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
+    auto kern = conv_wino_mfma<KD, TD, TR, CIC>;
+    const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(256), Cfg::LDS_BYTES, st, x, up, y, Ci, nchunks, Co, D,
+                       H, W, tiles_d, tiles_h, tiles_w);
+    return ECM_LAUNCH_RESULT();
+}
+
+constexpr int WINO_CIC3 = 2, WINO_CIC2 = 4;
+
+}  // namespace
+
+extern "C" long long ecm_conv_wino_packed_floats(int Ci, int Co, int kd) {
+    if (Ci <= 0 || Co <= 0 || (kd != 1 && kd != 3)) return 0;
+    const int cic = kd == 3 ? WINO_CIC3 : WINO_CIC2;
+    return (long long)((Co + 31) / 32) * ((Ci + cic - 1) / cic) * 16 * kd * cic * 32;
+}
+
+extern "C" int ecm_conv_wino_pack_weight(const float* w, float* packed, int Co, int Ci, int kd, int flip_transpose, void* stream) {
+    ECM_CHECK_ARG(w && packed && Co > 0 && Ci > 0 && (kd == 1 || kd == 3));
+    const int Kin = flip_transpose ? Co : Ci, Kout = flip_transpose ? Ci : Co;
+    const int cic = kd == 3 ? WINO_CIC3 : WINO_CIC2;
+    const int nchunks = (Kin + cic - 1) / cic;
+    const long long n = ecm_conv_wino_packed_floats(Kin, Kout, kd);
+    hipLaunchKernelGGL(pack_wino_weight, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ecm_stream(stream), w, packed, Co, Ci, kd,
+                       cic, nchunks, flip_transpose, n);
+    return ECM_LAUNCH_RESULT();
+}
+
+extern "C" int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int Ci, int Co, int D, int H, int W,
+                                 int kd, void* stream) {
+    ECM_CHECK_ARG(x && upacked && y && B > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0);
+    hipStream_t st = ecm_stream(stream);
+    if (kd == 3) return launch_wino<3, 2, 1, WINO_CIC3>(x, upacked, y, B, Ci, Co, D, H, W, st);
+    if (kd == 1 && D == 1) return launch_wino<1, 1, 2, WINO_CIC2>(x, upacked, y, B, Ci, Co, 1, H, W, st);
+    return ECM_EUNSUP;
+}

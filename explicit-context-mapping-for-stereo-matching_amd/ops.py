@@ -402,6 +402,35 @@ def _pack_deconv(w):
     return packed
 
 
+# Stride-1 3x3(x3) convolutions -- forward and data gradient -- run on the Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip):
+# 2.25x fewer matrix-core multiplies, fp32 throughout.  ECM_WINOGRAD=0 (or ops.WINOGRAD = False) selects the direct
+# implicit-GEMM kernels for everything; both are parity-tested.
+import os as _os
+WINOGRAD = _os.environ.get("ECM_WINOGRAD", "1") != "0"
+WINO2D_MIN_CI = 64
+
+
+def _wino_pack(w, kd, flip_transpose):
+    """w: [Co,Ci,3,3,3] (kd 3) or [Co,Ci,3,3] (kd 1), contiguous."""
+    Co, Ci = w.shape[:2]
+    kin, kout = (Co, Ci) if flip_transpose else (Ci, Co)
+
+    def build():
+        packed = torch.empty(_lib.query("ecm_conv_wino_packed_floats", kin, kout, kd), device=w.device, dtype=w.dtype)
+        _lib.call("ecm_conv_wino_pack_weight", _p(w), _p(packed), Co, Ci, kd, int(flip_transpose), _stream())
+        return packed
+    return _cached_pack(w, ("wT" if flip_transpose else "w") + str(kd), build)
+
+
+def _wino_run(x, packed, Co, kd):
+    """x: [B,Ci,D,H,W] (kd 3) or [B,Ci,H,W] (kd 1) -> same spatial shape with Co channels."""
+    B, Ci = x.shape[:2]
+    D, H, W = (x.shape[2:] if kd == 3 else (1,) + tuple(x.shape[2:]))
+    y = torch.empty((B, Co) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
+    _lib.call("ecm_conv_wino_fwd", _p(x), _p(packed), _p(y), B, Ci, Co, D, H, W, kd, _stream())
+    return y
+
+
 def _conv_fwd(x, packed, Co, stride):
     B, Ci, D, H, W = x.shape
     Do, Ho, Wo = (D - 1) // stride + 1, (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -440,6 +469,8 @@ class Conv3dK3(torch.autograd.Function):
             B, Ci, D, H, W = x.shape
             y = torch.empty(B, 1, D, H, W, device=x.device, dtype=x.dtype)
             _lib.call("ecm_conv3d_c1_fwd", _p(x), _p(w), _p(y), B, Ci, D, H, W, _stream())
+        elif stride == 1 and WINOGRAD:
+            y = _wino_run(x, _wino_pack(w, 3, False), w.shape[0], 3)
         else:
             y = _conv_fwd(x, _pack_conv(w), w.shape[0], stride)
         ctx.save_for_backward(x, w)
@@ -457,6 +488,8 @@ class Conv3dK3(torch.autograd.Function):
                 gx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
                 _lib.call("ecm_conv3d_c1_dgrad", _p(gy), _p(w), _p(gx), x.shape[0], Ci, x.shape[2], x.shape[3], x.shape[4],
                           _stream())
+            elif ctx.stride == 1 and WINOGRAD:
+                gx = _wino_run(gy, _wino_pack(w, 3, True), Ci, 3)
             elif ctx.stride == 1:
                 gx = _conv_fwd(gy, _pack_conv(w, True), Ci, 1) if Co % 4 == 0 else _dgrad_small_co(gy, w)
             else:
@@ -569,7 +602,14 @@ class Conv2dG(torch.autograd.Function):
         _chk(x, w)
         x = _c(x)
         Co, Ci, kh, kw = w.shape
-        y = _conv2d_run(x, _pack2d(w, False), Co, kh, kw, stride, dil, pad_top, pad_left, Ho, Wo)
+        same = (kh, kw, stride, dil, pad_top, pad_left) == (3, 3, 1, 1, 1, 1) and (Ho, Wo) == tuple(x.shape[-2:])
+        # Winograd where it is ahead of the direct kernel (tools/wino_time.py): from 64 input channels up -- with 32 the
+        # per-tile transform + exchange costs as much as the multiplies it saves
+        ctx.wino_f, ctx.wino_b = WINOGRAD and same and Ci >= WINO2D_MIN_CI, WINOGRAD and same and Co >= WINO2D_MIN_CI
+        if ctx.wino_f:
+            y = _wino_run(x, _wino_pack(_c(w), 1, False), Co, 1)
+        else:
+            y = _conv2d_run(x, _pack2d(w, False), Co, kh, kw, stride, dil, pad_top, pad_left, Ho, Wo)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, dil, pad_top, pad_left, Ho, Wo)
         return y
@@ -583,7 +623,9 @@ class Conv2dG(torch.autograd.Function):
         gy = _c(gy)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            if stride == 1:
+            if ctx.wino_b:
+                gx = _wino_run(gy, _wino_pack(_c(w), 1, True), Ci, 1)
+            elif stride == 1:
                 # gx[i] = sum_k w[k] gy[i + pad - k*dil]: the conv of gy with the flipped kernel, padding (K-1)*dil - pad
                 gx = _conv2d_run(gy, _pack2d(w, True), Ci, kh, kw, 1, dil, (kh - 1) * dil - pad_top, (kw - 1) * dil - pad_left,
                                  H, W)

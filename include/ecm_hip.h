@@ -125,6 +125,17 @@ int ecm_conv3d_pack_weight(const float* w, float* packed, int Co, int Ci, int fl
 int ecm_conv3d_k3_fwd(const float* x, const float* wpacked, float* y,
                       int B, int Ci, int Co, int D, int H, int W, int stride, void* stream);
 
+/* The same stride-1 convolution by Winograd F(2x2,3x3) in the (h,w) plane, direct along depth (conv_wino.hip): 2.25x fewer
+ * multiplies, fp32 throughout (transforms add/subtract/halve only; results differ from the direct kernel by fp32 rounding).
+ * kd = 3: Conv3d 3x3x3, x [B,Ci,D,H,W] -> y [B,Co,D,H,W];  kd = 1: Conv2d 3x3 (pass D = 1).  Any Ci, Co (32 output
+ * channels per workgroup; more go to a second grid dimension).  Weights: reference layout [Co,Ci,kd,3,3], transformed and
+ * packed by ecm_conv_wino_pack_weight (flip_transpose != 0: the data-gradient operator, Cin' = Co, Cout' = Ci; size query
+ * with the swapped counts). */
+long long ecm_conv_wino_packed_floats(int Ci, int Co, int kd);
+int ecm_conv_wino_pack_weight(const float* w, float* packed, int Co, int Ci, int kd, int flip_transpose, void* stream);
+int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int Ci, int Co, int D, int H, int W, int kd,
+                      void* stream);
+
 /* The classifier's last layer Conv3d(Ci<=32 -> 1) (cmfsm.py:624,629,634) on its own kernels: w is the reference weight
  * [1,Ci,3,3,3] (no packing); y: [B,1,D,H,W].  wgrad: gw [1,Ci,27] from x [B,Ci,D,H,W] and gy [B,1,D,H,W]. */
 int ecm_conv3d_c1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, void* stream);

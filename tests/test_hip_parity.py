@@ -678,3 +678,61 @@ def test_no_miopen_convolution_in_the_model(ecm):
         model = ecm.get_model(arch)
         enc = [m for m in model.feature_extraction.modules() if isinstance(m, torch.nn.Conv2d)]
         assert enc and all(isinstance(m, mdl.EncConv2d) and m._native() for m in enc), arch
+
+
+# ------------------------------------------------------------------ Winograd F(2x2,3x3) kernels (csrc/conv_wino.hip)
+@pytest.mark.parametrize("B,Ci,Co,dims", [(1, 32, 32, (4, 6, 64)), (2, 32, 32, (5, 7, 70)), (1, 64, 64, (3, 9, 33)), (1, 32, 64, (2, 4, 130)),
+                                          (1, 8, 12, (3, 5, 9)), (1, 32, 32, (1, 1, 1)), (1, 64, 32, (6, 13, 65))])
+def test_winograd_conv3d_vs_torch_and_direct(ecm, B, Ci, Co, dims):
+    """nn.Conv3d(k 3, stride 1, pad 1, bias=False) (convbn_3d, cmfsm.py:49-58) on the Winograd kernel: forward and data
+    gradient vs CPU F.conv3d autograd, and vs the direct implicit-GEMM kernel (same fp32 class; rounding differs)."""
+    x = seeded("wn.x", B, Ci, *dims)
+    w = seeded("wn.w", Co, Ci, 3, 3, 3) * (2.0 / (27 * Ci)) ** 0.5
+    xs, ws = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = F.conv3d(xs, ws, None, 1, 1)
+    G = seeded("wn.G", *ref.shape)
+    ref.backward(G)
+    res = {}
+    prev = ecm.ops.WINOGRAD
+    try:
+        for flag in (True, False):
+            ecm.ops.WINOGRAD = flag
+            xg, wg = dev(x).requires_grad_(), dev(w).requires_grad_()
+            y = ecm.ops.conv3d_k3(xg, wg, 1)
+            y.backward(dev(G))
+            res[flag] = (y.detach().cpu(), xg.grad.cpu(), wg.grad.cpu())
+    finally:
+        ecm.ops.WINOGRAD = prev
+    for flag in (True, False):
+        close(res[flag][0], ref, 1e-4, 2e-5)
+        close(res[flag][1], xs.grad, 1e-4, 2e-5)
+        close(res[flag][2], ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))
+    close(res[True][0], res[False][0], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 32, 32, 20, 64), (1, 64, 64, 33, 50), (1, 3, 32, 17, 37), (1, 128, 128, 9, 70), (1, 320, 128, 6, 34),
+                                         (2, 32, 480, 12, 40)])
+def test_winograd_conv2d_vs_torch(ecm, B, Ci, Co, H, W):
+    """The encoder's 3x3 / stride 1 / pad 1 Conv2d layers (cmfsm.py:36-46) and the P class convolution on the 2-D
+    instantiation of the Winograd kernel: forward + data gradient vs CPU F.conv2d autograd."""
+    assert ecm.ops.WINOGRAD
+    prev_min, ecm.ops.WINO2D_MIN_CI = ecm.ops.WINO2D_MIN_CI, 1          # every shape through the Winograd kernel here
+    try:
+        _winograd_conv2d_case(ecm, B, Ci, Co, H, W)
+    finally:
+        ecm.ops.WINO2D_MIN_CI = prev_min
+
+
+def _winograd_conv2d_case(ecm, B, Ci, Co, H, W):
+    x = seeded("wn2.x", B, Ci, H, W)
+    w = seeded("wn2.w", Co, Ci, 3, 3) * (2.0 / (9 * Ci)) ** 0.5
+    xs, ws = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = F.conv2d(xs, ws, None, 1, 1)
+    G = seeded("wn2.G", *ref.shape)
+    ref.backward(G)
+    xg, wg = dev(x).requires_grad_(), dev(w).requires_grad_()
+    y = ecm.ops.conv2d(xg, wg, 1, 1)
+    y.backward(dev(G))
+    close(y, ref, 1e-4, 2e-5)
+    close(xg.grad, xs.grad, 1e-4, 2e-5)
+    close(wg.grad, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))

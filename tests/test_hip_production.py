@@ -164,9 +164,10 @@ def ecm_weights9_torch(lr, hr, W0, W1, W2, W3, s=4):
         a = Ap[:, :, 1 + dy:1 + dy + h, 1 + dx:1 + dx + w].repeat_interleave(s, -1).repeat_interleave(s, -2)
         valid = ok[:, :, 1 + dy:1 + dy + h, 1 + dx:1 + dx + w].repeat_interleave(s, -1).repeat_interleave(s, -2)
         z = _leaky(a + Bv + w0[:, 64].view(1, 32, 1, 1) * offx + w0[:, 65].view(1, 32, 1, 1) * offy)
-        z = _leaky(F.conv2d(z, W1))
-        z = _leaky(F.conv2d(z, W2))
-        z = F.conv2d(z, W3)
+        # 1x1 convolutions as einsums: plain GEMM-free torch arithmetic in any dtype (MIOpen has no fp64 convolution)
+        z = _leaky(torch.einsum("oc,bchw->bohw", W1.view(16, 32), z))
+        z = _leaky(torch.einsum("oc,bchw->bohw", W2.view(8, 16), z))
+        z = torch.einsum("oc,bchw->bohw", W3.view(1, 8), z)
         logits.append(torch.where(valid > 0, z, torch.full_like(z, -100.0)))
     return F.softmax(torch.cat(logits, 1), 1)
 

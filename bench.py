@@ -205,7 +205,7 @@ def main():
         note(f"warmup step {i + 1}/{args.warmup} done")
     # time EXACTLY K steps; the dominant kernels and the worst-roofline kernels are also event-timed per launch on the
     # launch stream
-    TIMED = ("ecm_conv3d_k3_fwd", "ecm_conv3d_k3_wgrad", "ecm_conv3d_c1_fwd", "ecm_weights9_fwd")
+    TIMED = ("ecm_conv_wino_fwd", "ecm_conv3d_k3_fwd", "ecm_conv3d_k3_wgrad", "ecm_conv3d_c1_fwd", "ecm_weights9_fwd")
     for name in TIMED:
         lib.enable_timer(name)
     barrier()
@@ -312,10 +312,13 @@ def main():
         def ms_of(evs):
             return sum(s.elapsed_time(e) for s, e in evs) / max(1, len(evs))
 
-        # dominant kernel SYMBOL: conv3d_k3_mfma<1,1,4,8,4> = every ecm_conv3d_k3_fwd launch with stride 1 and Co <= 32
-        # (forward convs, and in training the stride-1 data gradients that run on the same kernel).
-        # int args of the call: (B, Ci, Co, D, H, W, stride).  achieved = sum(algorithmic FLOPs) / sum(duration).
-        sel = [(s, e, a) for (s, e, a) in timers.get("ecm_conv3d_k3_fwd", []) if a[6] == 1 and a[2] <= 32]
+        # dominant kernel SYMBOL: the stride-1 3x3x3 convolutions with <= 32 output channels (forward convs and, in training,
+        # their data gradients) = every ecm_conv_wino_fwd launch with kd == 3 and Co <= 32 (conv_wino_mfma<3,2,1,2>), or with
+        # ECM_WINOGRAD=0 every ecm_conv3d_k3_fwd launch with stride 1 (conv3d_k3_mfma<1,1,4,8,4>).
+        # achieved = sum(ALGORITHMIC FLOPs = 2*27*Ci*Co*voxels, the direct-convolution count of SURVEY 8d) / sum(duration).
+        wino = [(s, e, a) for (s, e, a) in timers.get("ecm_conv_wino_fwd", []) if a[6] == 3 and a[2] <= 32]   # (B,Ci,Co,D,H,W,kd)
+        direct = [(s, e, a) for (s, e, a) in timers.get("ecm_conv3d_k3_fwd", []) if a[6] == 1 and a[2] <= 32]  # (..., stride)
+        sel = wino if wino else direct
         conv_total_ms = sum(s.elapsed_time(e) for s, e, _ in sel)
         conv_ms = conv_total_ms / max(1, len(sel))
         conv_flop = sum(2.0 * 27 * a[1] * a[2] * a[3] * a[4] * a[5] * a[0] for _, _, a in sel)
@@ -323,6 +326,9 @@ def main():
         main_l = [(s, e) for (s, e, a) in sel if a[1] == 32 and a[2] == 32]
         main_ms = ms_of(main_l)
         main_tf = 2.0 * 27 * 32 * 32 * Dl * h * w * B / (main_ms * 1e-3) / 1e12 if main_l else 0.0
+        executed = 12.0 / 27.0 if wino else 1.0      # Winograd F(2x2,3x3) x direct depth: 16 multiplies per 4 outputs per kd
+        conv_kernel = ("conv_wino_mfma<3,2,1,2> (Winograd F(2x2,3x3) in (h,w), direct along d; all stride-1 3x3x3, Co<=32 launches: fwd + dgrad)"
+                       if wino else "conv3d_k3_mfma<1,1,4,8,4> (all stride-1, Co<=32 launches: fwd + dgrad)")
         cv = [(s, e) for (s, e, a) in timers["ecm_costvol_concat_fwd"]]
         cv_ms = ms_of(cv)
         cv_bytes = (2 * 32 * Dl * h * w + 2 * 32 * h * w) * 4.0 * B
@@ -389,9 +395,15 @@ def main():
                        "cost_volume": "explicit 4-D tensor" if args.explicit_cost_volume else "collapsed into class-indexed 2-D convolutions",
                        "launch": "hip graph replay" if (args.mode == "infer" and args.graph) else "eager"},
             "ms_per_cost_volume": cv_ms / B,
-            "roofline": {"kernel": "conv3d_k3_mfma<1,1,4,8,4> (all stride-1, Co<=32 launches: fwd + dgrad)", "bound": "mfma",
+            "roofline": {"kernel": conv_kernel, "bound": "mfma",
                          "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_conv, "traffic_note": traffic_note,
+                         "frac": conv_tf / PEAK_F32_MFMA_TFLOPS,
+                         "executed_mfma_tflops": conv_tf * executed, "executed_frac_of_peak": conv_tf * executed / PEAK_F32_MFMA_TFLOPS,
+                         "note": "achieved counts the ALGORITHMIC (direct-convolution) FLOPs; the Winograd kernel executes 12/27 of "
+                                 "them on the matrix cores (executed_*), which is how `frac` can exceed 1" if wino else
+                                 "direct implicit GEMM: algorithmic == executed FLOPs",
+                         "traffic": traffic_conv if not wino else None,
+                         "traffic_note": traffic_note if not wino else "PMC pass on file is for the direct kernel (profiles/r02_pmc_traffic.json)",
                          "launches_timed": len(sel), "avg_launch_ms": conv_ms,
                          "of_which_32to32": {"achieved": main_tf, "frac": main_tf / PEAK_F32_MFMA_TFLOPS,
                                              "avg_launch_ms": main_ms, "launches_timed": len(main_l)}},

@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     constexpr int NUQ = (UF / 4 + 255) / 256;                // weight float4s per thread per chunk
     static_assert(UF % 4 == 0, "weight chunk moves as float4");
 
-    float raw[16];
-    auto load_raw = [&](int chunk) {
+    // Patches are fetched TWO chunks ahead of their transform (two register buffers, used alternately by even / odd chunks):
+    // the 16 loads then have a whole chunk's worth of MFMAs to land, so the transform never waits for memory.
+    float rawA[16], rawB[16];
+    auto load_raw = [&](int chunk, float (&raw)[16]) {
         const int c = chunk * CIC + pc_u;
         const bool live = c < Ci;                            // channel padding: an empty descriptor reads zeros
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(live ? c : 0) * DHWi), 0,
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     // V = B^T d B of the patch in `raw` -> Vs image `dst`: 16 frequency planes, this thread's (pc, pz, pr, t) slot.
     // Two halves so that each fits into the shadow of one group of MFMAs in the main loop.
     float tmp[16];
-    auto transform_rows = [&]() {
+    auto transform_rows = [&](const float (&raw)[16]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                        // rows: B^T d
             const float d0 = raw[j], d1 = raw[4 + j], d2 = raw[8 + j], d3 = raw[12 + j];
@@ -146,30 +148,38 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = clock64();
 #endif
     // ---- prologue: chunk 0 into buffer 0, chunk 1's patch into registers -------------------------------------------------
+    // chunk c's patch lives in rawA for even c, rawB for odd c
+    load_raw(0, rawA);
     dma_u(0, Us);
-    load_raw(0);
-    transform_rows();
-    transform_cols_store(Vs);
-    if (nchunks > 1) {
-        load_raw(1);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the weight DMA (older than the 16 patch loads) has landed
+    if (nchunks > 1) load_raw(1, rawB);
+    if (nchunks > 2) {
+        // chunk 0's patch (the oldest 16 loads) is needed now; chunk 1's may stay in flight
+        transform_rows(rawA);                                // the compiler waits for exactly the loads it reads
+        transform_cols_store(Vs);
+        load_raw(2, rawA);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // DMA of chunk 0 (older than chunk 2's 16 loads) has landed
     } else {
+        transform_rows(rawA);
+        transform_cols_store(Vs);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // raw barrier: see the main loop
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     WN_T(0);
 
-    for (int c = 0; c < nchunks; ++c) {
+    // One chunk; PAR = c & 1 picks the register buffer that holds chunk c+1's patch (and receives chunk c+3's).
+    auto chunk_body = [&](int c, float (&raw_next)[16]) {
         const int buf = c & 1;
         const float* Vc = Vs + buf * VF;
         const float* Uc = Us + buf * UF;
         float* Vn = Vs + (buf ^ 1) * VF;
-        // (1) every MFMA operand of this chunk into registers with ONE burst of LDS reads (left to itself hipcc reads two or
-        //     three operands at a time and waits lgkmcnt(0) in front of every small group of MFMAs: ~8 exposed LDS latencies
-        //     per 24 MFMAs)
+        const bool more = c + 1 < nchunks, more3 = c + 3 < nchunks;
+        // (1) MFMA operands of this chunk into registers: frequency 0 first, so that its MFMAs can start as soon as ITS reads
+        //     are back while the other three groups' reads are still in flight
         float av[4][CIC / 2][KD], bw[4][CIC / 2][NP][TR];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < 4; ++f) {
 #pragma unroll
             for (int kk = 0; kk < CIC / 2; ++kk) {
                 const int xi = wave * 4 + f;
@@ -181,13 +191,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
 #pragma unroll
                 for (int kd = 0; kd < KD; ++kd) av[f][kk][kd] = Uc[((xi * KD + kd) * CIC + kk * 2 + half) * 32 + l31];
             }
+            if (f == 0) __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         WN_T(1);
         // (2) the MFMAs, one frequency (KD*CIC/2*NPR of them) at a time, each group followed by a slice of the staging work
-        //     for the chunks ahead, small enough to issue in the shadow of the group's last MFMA: the next chunk's patch
-        //     (loaded during the previous iteration) -> the other V buffer, next chunk's weights (DMA), the patch after it
-        //     -> registers.  sched_barriers pin that interleave.
-        const bool more = c + 1 < nchunks, more2 = c + 2 < nchunks;
+        //     for the chunks ahead, small enough to issue in the shadow of the group's last MFMA.  sched_barriers pin it.
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
 #pragma unroll
@@ -200,19 +209,28 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
                         for (int r = 0; r < TR; ++r)
                             acc[f][p * TR + r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f][kk][kd], bw[f][kk][p + kd][r],
                                                                                       acc[f][p * TR + r], 0, 0, 0);
-            if (f == 0 && more) transform_rows();
+            if (f == 0 && more) transform_rows(raw_next);                 // chunk c+1's patch: loaded two chunks ago
             if (f == 1 && more) transform_cols_store(Vn);
             if (f == 2 && more) dma_u(c + 1, Us + (buf ^ 1) * UF);
-            if (f == 3 && more2) load_raw(c + 2);
+            if (f == 3 && more3) load_raw(c + 3, raw_next);               // the buffer just consumed gets chunk c+3's patch
             __builtin_amdgcn_sched_barrier(0);
         }
         WN_T(2);
-        // weight DMA of chunk c+1 landed: it is older than the 16 patch loads of chunk c+2, the only younger VMEM operations
-        if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        // weight DMA of chunk c+1 landed: the only VMEM operations younger than it are the 16 patch loads of chunk c+3
+        // (chunk c+2's, issued one chunk earlier, are older and are waited for with it -- they have had a full chunk)
+        if (more3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WN_T(3);
-        __syncthreads();
+        // NOT __syncthreads(): its workgroup fence waits vmcnt(0), i.e. for the 16 patch loads issued a moment ago -- a full
+        // memory round trip per chunk.  Own LDS writes done + raw barrier is all the hand-off of V / U needs.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         WN_T(4);
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk_body(c, rawB);                                 // chunk c even: chunk c+1's patch is in rawB
+        if (c + 1 < nchunks) chunk_body(c + 1, rawA);
     }
 
     // ---- epilogue: Y = A^T M A.  Wave w owns frequency ROW i = w (xi = 4w + j), so the column half of the transform,

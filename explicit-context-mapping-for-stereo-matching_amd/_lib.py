@@ -49,11 +49,6 @@ PROTOTYPES = {
     "ecm_deconv3d_k3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_conv3d_wgrad_scratch_bytes": (_LL, [_I, _I, _I, _I, _I, _I, _I]),
     "ecm_conv3d_k3_wgrad": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "ecm_conv2d_packed_floats": (_LL, [_I, _I]),
-    "ecm_conv2d_pack_weight": (_I, [_P, _P, _I, _I, _I, _P]),
-    "ecm_conv2d_k3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "ecm_conv2d_k3_wgrad_scratch_bytes": (_LL, [_I] * 5),
-    "ecm_conv2d_k3_wgrad": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
     "ecm_conv2d_packed_floats_ex": (_LL, [_I] * 4),
     "ecm_conv2d_pack_weight_ex": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "ecm_conv2d_fwd_ex": (_I, [_P, _P, _P] + [_I] * 13 + [_P]),

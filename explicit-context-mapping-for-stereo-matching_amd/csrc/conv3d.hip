@@ -28,8 +28,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TW = 32;
 
-// KD = 3: the 3x3x3 Conv3d.  KD = 1: a 3x3 Conv2d as a depth-1 volume with no taps / padding along depth (the encoder's
-// 32- and 64-channel convbn layers, cmfsm.py:37-47): same kernel, 9 taps.
+// KD = 3: the 3x3x3 Conv3d (the 2-D layers have their own family in conv2d.hip, the stride-1 layers run by default on the
+// Winograd kernel of conv_wino.hip).
 template <int CO_TILES, int STRIDE, int TD, int TH, int CIC, int KD = 3>
 struct ConvCfg {
     static constexpr int NTAPS = 9 * KD;
@@ -261,38 +261,6 @@ extern "C" int ecm_conv3d_pack_weight(const float* w, float* packed, int Co, int
     hipLaunchKernelGGL(pack_conv_weight, dim3((n + 255) / 256), dim3(256), 0, ecm_stream(stream), w, packed, Co, Ci, cop,
                        flip_transpose, 27);
     return ECM_LAUNCH_RESULT();
-}
-
-// ---- 3x3 Conv2d, stride 1, pad 1 (the encoder's 32/64-channel layers): depth-1 volume, 9 taps -----------------------
-extern "C" long long ecm_conv2d_packed_floats(int Ci, int Co) {
-    const long long cop = ((Co + 31) / 32) * 32;
-    return 9LL * Ci * cop;
-}
-
-extern "C" int ecm_conv2d_pack_weight(const float* w, float* packed, int Co, int Ci, int flip_transpose, void* stream) {
-    ECM_CHECK_ARG(w && packed && Co > 0 && Ci > 0);
-    const int Kin = flip_transpose ? Co : Ci, Kout = flip_transpose ? Ci : Co;
-    const int cop = ((Kout + 31) / 32) * 32;
-    const int n = 9 * Kin * cop;
-    hipLaunchKernelGGL(pack_conv_weight, dim3((n + 255) / 256), dim3(256), 0, ecm_stream(stream), w, packed, Co, Ci, cop,
-                       flip_transpose, 9);
-    return ECM_LAUNCH_RESULT();
-}
-
-extern "C" int ecm_conv2d_k3_fwd(const float* x, const float* wpacked, float* y, int B, int Ci, int Co, int H, int W,
-                                 void* stream) {
-    ECM_CHECK_ARG(x && wpacked && y && B > 0 && H > 0 && W > 0);
-    if (Ci % 8 != 0 || Co < 1 || Co > 64) return ECM_EUNSUP;
-    hipStream_t st = ecm_stream(stream);
-    // tile height by image size: 32 rows per workgroup when that still gives >= 3 rounds of workgroups, else 16 / 8
-    // (measured, 8 images: 32->32 at 576x960 0.75 ms with 32 rows; 64->64 at 144x240 0.222 ms with 16 rows, 0.186 with 8)
-    const long long cols = (long long)B * ((W + TW - 1) / TW);
-    if (Co <= 32) {
-        if (cols * ((H + 31) / 32) >= 1536) return launch_conv<1, 1, 1, 32, 4, 1>(x, wpacked, y, B, Ci, Co, 1, H, W, st);
-        return launch_conv<1, 1, 1, 16, 8, 1>(x, wpacked, y, B, Ci, Co, 1, H, W, st);
-    }
-    if (cols * ((H + 15) / 16) >= 1536) return launch_conv<2, 1, 1, 16, 8, 1>(x, wpacked, y, B, Ci, Co, 1, H, W, st);
-    return launch_conv<2, 1, 1, 8, 8, 1>(x, wpacked, y, B, Ci, Co, 1, H, W, st);
 }
 
 extern "C" int ecm_conv3d_k3_fwd(const float* x, const float* wpacked, float* y, int B, int Ci, int Co, int D, int H,

@@ -339,25 +339,6 @@ extern "C" int ecm_conv3d_k3_wgrad(const float* x, const float* gy, float* gw, v
     return launch_wgrad<2, 1, 4, 3>(x, gy, gw, partial, B, Ci, Co, D, H, W, st);
 }
 
-// ---- 3x3 Conv2d (stride 1, pad 1): 16 x 16 output tiles of a depth-1 volume -------------------------------------
-namespace {
-inline long long ntiles2d(int B, int H, int W) { return (long long)B * ((H + 15) / 16) * ((W + TWV - 1) / TWV); }
-}  // namespace
-
-extern "C" long long ecm_conv2d_k3_wgrad_scratch_bytes(int B, int Ci, int Co, int H, int W) {
-    if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;
-    return (long long)wgrad_workers(Ci, Co, ntiles2d(B, H, W), 2) * 2 * Co * Ci * 9 * (long long)sizeof(float);
-}
-
-extern "C" int ecm_conv2d_k3_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
-                                   int B, int Ci, int Co, int H, int W, void* stream) {
-    ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && Co > 0 && H > 0 && W > 0);
-    if ((long long)H * W * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;
-    if (ntiles2d(B, H, W) >= 0x7fffffffLL) return ECM_EUNSUP;
-    if (scratch_bytes < ecm_conv2d_k3_wgrad_scratch_bytes(B, Ci, Co, H, W)) return ECM_ESCRATCH;
-    return launch_wgrad<1, 1, 16, 1>(x, gy, gw, static_cast<float*>(scratch), B, Ci, Co, 1, H, W, ecm_stream(stream));
-}
-
 // ---- general 2-D weight gradient: KH x KW in {3x3, 3x5, 1x1}, stride 1|2, dilation 1|2|4, explicit padding / output size
 namespace {
 inline long long ntiles2d_ex(int B, int Ho, int Wo, int stride) {

@@ -469,8 +469,8 @@ class six_related_context_mapping(nn.Module):
 
 class _ECMNet(nn.Module):
     """Shared skeleton of the registered architectures: encoder -> cost volume -> dres0/1 -> 1 or 3 hourglasses ->
-    classifiers -> head.  Subclasses set ENCODER, HOURGLASSES, HEAD, ACCUMULATE exactly as their reference file does."""
-    ENCODER, HOURGLASSES, HEAD, ACCUMULATE, SIM2 = "cmfsm", 3, "eight", True, False
+    classifiers -> head.  Subclasses set ENCODER, HOURGLASSES and HEAD exactly as their reference file does."""
+    ENCODER, HOURGLASSES, HEAD, SIM2 = "cmfsm", 3, "eight", False
 
     def __init__(self, maxdisp=192):
         super().__init__()
@@ -535,35 +535,35 @@ class _ECMNet(nn.Module):
 
 
 class cmfsm_sub_8(_ECMNet):
-    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub8", 3, "five", False
+    ENCODER, HOURGLASSES, HEAD = "sub8", 3, "five"
 
 
 class cmfsm_sub_16(_ECMNet):
-    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub16", 3, "volume", True
+    ENCODER, HOURGLASSES, HEAD = "sub16", 3, "volume"
 
 
 class cm_sub_4(_ECMNet):
-    ENCODER, HOURGLASSES, HEAD, ACCUMULATE, SIM2 = "sub4", 1, "volume", False, True
+    ENCODER, HOURGLASSES, HEAD, SIM2 = "sub4", 1, "volume", True
 
 
 class cm_sub_8(_ECMNet):
-    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub8", 1, "volume", False
+    ENCODER, HOURGLASSES, HEAD = "sub8", 1, "volume"
 
 
 class cm_sub_16(_ECMNet):
-    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub16", 1, "volume", False
+    ENCODER, HOURGLASSES, HEAD = "sub16", 1, "volume"
 
 
 class bilinear_cmf(_ECMNet):
-    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub4", 3, "trilinear", True
+    ENCODER, HOURGLASSES, HEAD = "sub4", 3, "trilinear"
 
 
 class bilinear_cmf_sub_8(_ECMNet):
-    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub8", 3, "trilinear", True
+    ENCODER, HOURGLASSES, HEAD = "sub8", 3, "trilinear"
 
 
 class bilinear_cmf_sub_16(_ECMNet):
-    ENCODER, HOURGLASSES, HEAD, ACCUMULATE = "sub16", 3, "trilinear", True
+    ENCODER, HOURGLASSES, HEAD = "sub16", 3, "trilinear"
 
 
 _MODELS = {"cmfsm": cmfsm, "cmfsm_sub_8": cmfsm_sub_8, "cmfsm_sub_16": cmfsm_sub_16, "cm_sub_4": cm_sub_4,

@@ -491,7 +491,7 @@ class Conv3dK3(torch.autograd.Function):
             elif ctx.stride == 1 and WINOGRAD:
                 gx = _wino_run(gy, _wino_pack(w, 3, True), Ci, 3)
             elif ctx.stride == 1:
-                gx = _conv_fwd(gy, _pack_conv(w, True), Ci, 1) if Co % 4 == 0 else _dgrad_small_co(gy, w)
+                gx = _conv_fwd(gy, _pack_conv(w, True), Ci, 1)
             else:
                 gx = _deconv_fwd(gy, _pack_deconv(w), Ci, x.shape[2:])
         if ctx.needs_input_grad[1]:
@@ -510,18 +510,6 @@ class Conv3dK3(torch.autograd.Function):
 def _is_c1(w, stride):
     """The classifier's 32 -> 1 layer has its own kernels (conv3d_c1.hip)."""
     return w.shape[0] == 1 and stride == 1 and w.shape[1] <= 32 and w.shape[1] % 8 == 0
-
-
-def _dgrad_small_co(gy, w):
-    """Data gradient of the Cout=1 classifier conv (cmfsm.py:624): pad gy's channel dim to 4 (zeros) so the
-    MFMA kernel's k-steps stay whole."""
-    B, Co, D, H, W = gy.shape
-    Ci = w.shape[1]
-    gyp = torch.zeros(B, 4, D, H, W, device=gy.device, dtype=gy.dtype)
-    gyp[:, :Co] = gy
-    wp = torch.zeros(4, Ci, 3, 3, 3, device=w.device, dtype=w.dtype)
-    wp[:Co] = w
-    return _conv_fwd(gyp, _pack_conv(wp, True), Ci, 1)
 
 
 # Packed-weight cache: the packed layouts ride on the weight tensor OBJECT (an attribute), tagged with its version counter

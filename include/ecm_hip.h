@@ -159,21 +159,6 @@ long long ecm_conv3d_wgrad_scratch_bytes(int B, int Ci, int Co, int D, int H, in
 int ecm_conv3d_k3_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
                         int B, int Ci, int Co, int D, int H, int W, int stride, void* stream);
 
-/* The encoder's 3x3 Conv2d (stride 1, pad 1, dilation 1, no bias; convbn, cmfsm.py:37-47) on the same implicit-GEMM
- * kernel as ecm_conv3d_k3_fwd (depth-1 volume, 9 taps).  packed: 9*Ci*CoP floats from ecm_conv2d_pack_weight (weight
- * [Co,Ci,3,3]; flip_transpose = 1 packs the data-gradient operator, i.e. dgrad = ecm_conv2d_k3_fwd(gy, packed_T, Ci)).
- * Ci % 8 == 0, Co <= 64. */
-long long ecm_conv2d_packed_floats(int Ci, int Co);
-int ecm_conv2d_pack_weight(const float* w, float* packed, int Co, int Ci, int flip_transpose, void* stream);
-int ecm_conv2d_k3_fwd(const float* x, const float* wpacked, float* y, int B, int Ci, int Co, int H, int W, void* stream);
-
-/* Weight gradient of the encoder's 3x3 Conv2d (stride 1, pad 1, dilation 1, no bias; convbn, cmfsm.py:37-47):
- * gw[co,ci,3,3] = sum_{b,o} gy[b,co,o] * x[b,ci,o+k-1].  Same kernel as ecm_conv3d_k3_wgrad on a depth-1 volume with 9 taps.
- * x: [B,Ci,H,W], gy: [B,Co,H,W]; scratch >= ecm_conv2d_k3_wgrad_scratch_bytes(...) */
-long long ecm_conv2d_k3_wgrad_scratch_bytes(int B, int Ci, int Co, int H, int W);
-int ecm_conv2d_k3_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
-                        int B, int Ci, int Co, int H, int W, void* stream);
-
 /* General 2-D convolution family (conv2d.hip), same implicit-GEMM kernel: the encoder's Conv2d layers (feature_extraction,
  * cmfsm.py:126-236: 3x3 with stride 1|2 and dilation 1|2|4, the 3-channel stem, 64/128/320-channel stages, 1x1 projections),
  * the class-indexed convolutions of the collapsed cost volume (3x3 32->480, sheared 3x5 32->192; cmfsm.py:667-684) and all

@@ -233,7 +233,7 @@ def test_conv3d_fwd(ecm, B, Ci, Co, dims, stride):
 @pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 32, 32, 20, 40), (1, 64, 64, 33, 50), (1, 32, 64, 16, 16), (2, 64, 32, 48, 70),
                                          (1, 32, 32, 5, 7)])
 def test_conv2d_k3_wgrad(ecm, B, Ci, Co, H, W):
-    """Encoder 3x3 Conv2d: MIOpen forward / dgrad + MFMA weight gradient == autograd of F.conv2d on the CPU."""
+    """Encoder 3x3 / stride 1 Conv2d on the native 2-D family (forward, data and weight gradient) == autograd of F.conv2d."""
     x = seeded("cv2.x", B, Ci, H, W)
     w = seeded("cv2.w", Co, Ci, 3, 3) * (2.0 / (9 * Ci)) ** 0.5
     G = seeded("cv2.G", B, Co, H, W)

@@ -97,7 +97,96 @@ __device__ __forceinline__ void wg_tile(const float* __restrict__ ga, const floa
     }
 }
 
-template <int STRIDE, int TD, int TH, int KD, int KH = 3, int KW = 3, int DIL = 1>
+// ---- Winograd F(2x2,3x3) form of the stride-1 weight gradient (direct along depth) ---------------------------------------
+//   gw = G^T [ sum_tiles (A gy_tile A^T) (.) (B^T x_patch B) ] G
+// per 2x2 output tile: 16 multiplies per (co, ci, kd) instead of 36.  Frequency (i,j): wave i owns row i, i.e. the four
+// accumulators j = 0..3 per depth tap.  The operands are NOT staged in transformed form: every lane builds them on the fly
+// from the SAME raw LDS tiles the direct kernel uses (x halo tile [ci][dz][hy][xx], gy tile [co][voxels]) -- for its
+// frequency row a patch contributes two of its four rows, so a B fragment costs 8 LDS reads + 8 adds per four operands, an A
+// fragment 4 reads + 4 adds -- so staging, prefetch pipeline and LDS footprint are exactly the direct kernel's.
+// GEMM per frequency: D[co][ci] += sum_tile A[co][tile] B[tile][ci]; a k-step = two x-adjacent tiles (lane half = tile).
+template <int TD, int TH, int KD, int I, int NLOADS, class Issue>
+__device__ __forceinline__ void wg_tile_wino(const float* __restrict__ gaw, const float* __restrict__ xbw,
+                                             f32x16 (&acc)[4 * KD], Issue&& issue) {
+    using Cfg = WgCfg<1, TD, TH, KD>;
+    constexpr int IH = Cfg::IH, RS = Cfg::RS, NP = TD + KD - 1;
+    constexpr int PAIRS = TWV / 4, KS = (TH / 2) * PAIRS;                 // k-steps: tile rows x pairs of tiles
+    // frequency row I of B^T d: rows (RA, RB) of the patch, RA - RB (I = 1: RA + RB)
+    constexpr int RA = I == 0 ? 0 : I == 2 ? 2 : 1, RB = I == 0 ? 2 : I == 1 ? 2 : I == 2 ? 1 : 3;
+    // Register budget (one wave per SIMD, 512 registers): 4*KD accumulators (192) + the next tile's prefetch registers (104)
+    // leave room for ONE set of raw operands: the reads of k-step ks+1 are issued before the MFMAs of ks and turned into
+    // operands after them, in the shadow of the last MFMAs.
+    float xr_[NP][2][4], gr_[TD][2][2];                                   // raw operands of the NEXT k-step: [plane][row][column]
+    float bq[NP][4], aq[TD][4];                                           // operands of the current k-step
+    auto read_raw = [&](int ks) {                                         // ks is wave-uniform: scalar address arithmetic
+        const int tr = ks / PAIRS, pr = ks % PAIRS;
+        const float* xk = xbw + 2 * tr * RS + 4 * pr;
+        const float* gk = gaw + 2 * tr * TWV + 4 * pr;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xr_[p][0][j] = xk[(p * IH + RA) * RS + j];
+                xr_[p][1][j] = xk[(p * IH + RB) * RS + j];
+            }
+#pragma unroll
+        for (int d = 0; d < TD; ++d)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) gr_[d][r][c] = gk[(d * TH + r) * TWV + c];
+    };
+    auto make_operands = [&]() {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = I == 1 ? xr_[p][0][j] + xr_[p][1][j] : xr_[p][0][j] - xr_[p][1][j];
+            bq[p][0] = e[0] - e[2]; bq[p][1] = e[1] + e[2]; bq[p][2] = e[2] - e[1]; bq[p][3] = e[1] - e[3];
+        }
+#pragma unroll
+        for (int d = 0; d < TD; ++d) {
+            // row I of A g: g0 | g0 + g1 | g0 - g1 | -g1; then columns m0 | m0 + m1 | m0 - m1 | -m1
+            float m[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                m[c] = I == 0 ? gr_[d][0][c] : I == 1 ? gr_[d][0][c] + gr_[d][1][c]
+                     : I == 2 ? gr_[d][0][c] - gr_[d][1][c] : -gr_[d][1][c];
+            aq[d][0] = m[0]; aq[d][1] = m[0] + m[1]; aq[d][2] = m[0] - m[1]; aq[d][3] = -m[1];
+        }
+    };
+    // The k-step loop stays ROLLED (fully unrolled, hipcc's register allocation of 16 x 24 MFMAs with the interleaved
+    // prefetch spills ~200 registers); the next tile's global loads are issued in NPH bursts between groups of k-steps.
+    constexpr int NPH = 4, KPP = KS / NPH, LPP = (NLOADS + NPH - 2) / (NPH - 1);   // bursts in the first NPH-1 phases
+    static_assert(KS % NPH == 0, "k-steps split into phases");
+    read_raw(0);
+    make_operands();
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        if (ph < NPH - 1) {
+#pragma unroll
+            for (int q = 0; q < LPP; ++q)
+                if (ph * LPP + q < NLOADS) issue(ph * LPP + q);
+        }
+#pragma unroll 1
+        for (int ks = ph * KPP; ks < (ph + 1) * KPP; ++ks) {
+            if (ks + 1 < KS) read_raw(ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+                    for (int d = 0; d < TD; ++d)
+                        acc[j * KD + kd] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[d][j], bq[d + kd][j], acc[j * KD + kd], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);     // the reads above stay ahead of these MFMAs, the transform below behind them
+            if (ks + 1 < KS) make_operands();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int STRIDE, int TD, int TH, int KD, int KH = 3, int KW = 3, int DIL = 1, bool WINO = false>
 __global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
                                                          float* __restrict__ partial, int B, int Ci, int Co, int D,
                                                          int H, int W, int Do, int Ho, int Wo, int tiles_d, int tiles_h,
@@ -114,9 +203,11 @@ __global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const 
     const int ci0 = (blockIdx.y % ci_tiles) * CT, co0 = (blockIdx.y / ci_tiles) * CT;
     const int tgi = wave % Cfg::TG, kgi = wave / Cfg::TG;      // tap group, k-step group of this wave
     const int t0 = tgi * MAXNT;                                // this wave's taps [t0, t0+nt)
-    f32x16 acc[MAXNT];
+    constexpr int NACC = WINO ? 4 * KD : MAXNT;                // Winograd: frequencies j = 0..3 x depth taps, wave = frequency row
+    static_assert(!WINO || (STRIDE == 1 && KH == 3 && KW == 3 && DIL == 1 && TH % 2 == 0), "Winograd form: 3x3, stride 1");
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < MAXNT; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -223,6 +314,16 @@ __global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const 
         WG_T(3);
         prefetch_setup(tile + tile_step < tile_end ? tile + tile_step : (unsigned)ntiles);
         WG_T(4);
+        if constexpr (WINO) {
+            const float* gaw = Gs + l31 * GSTR + half * 2;       // lane half = which of the k-step's two tiles
+            const float* xbw = Xs + l31 * XSTR + half * 2;
+            switch (wave) {      // wave-uniform: the frequency row is a compile-time constant
+                case 0: wg_tile_wino<TD, TH, KD, 0, NLOADS>(gaw, xbw, acc, prefetch_issue); break;
+                case 1: wg_tile_wino<TD, TH, KD, 1, NLOADS>(gaw, xbw, acc, prefetch_issue); break;
+                case 2: wg_tile_wino<TD, TH, KD, 2, NLOADS>(gaw, xbw, acc, prefetch_issue); break;
+                default: wg_tile_wino<TD, TH, KD, 3, NLOADS>(gaw, xbw, acc, prefetch_issue); break;
+            }
+        } else {
         const float* ga = Gs + l31 * GSTR + half;
         const float* xb = Xs + l31 * XSTR + half * STRIDE;
         switch (wave) {          // wave-uniform: makes every tap offset a compile-time immediate
@@ -231,12 +332,28 @@ __global__ __launch_bounds__(256, KD == 3 ? 1 : 2) void conv3d_wgrad_mfma(const 
             case 2: wg_tile<STRIDE, TD, TH, KD, KH, KW, DIL, 2 % Cfg::TG, 2 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
             default: wg_tile<STRIDE, TD, TH, KD, KH, KW, DIL, 3 % Cfg::TG, 3 / Cfg::TG, NLOADS>(ga, xb, acc, prefetch_issue); break;
         }
+        }
         WG_T(5);
     }
 #ifdef WG_PROFILE
     if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
         for (int i = 0; i < 8; ++i) wg_prof[wave * 8 + i] = prof[i];
 #endif
+    if constexpr (WINO) {
+        // partial[blockIdx.x][xi = 4*wave + j][kd][co][ci]   (Winograd domain; wgrad_wino_finish applies G^T . G)
+        float* pw = partial + (size_t)blockIdx.x * 16 * KD * Co * Ci;
+        const int ci = ci0 + l31;
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) {
+            const int j = t / KD, kd = t % KD;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                if (co < Co && ci < Ci) pw[((size_t)((wave * 4 + j) * KD + kd) * Co + co) * Ci + ci] = acc[t][i];
+            }
+        }
+        return;
+    }
     // ---- write this wave's partial: partial[blockIdx.x * KG + k-group][co][ci][tap] -------------------
     float* pp = partial + ((size_t)blockIdx.x * Cfg::KG + kgi) * Co * Ci * NTAPS;
 #pragma unroll
@@ -282,6 +399,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
     }
 }
 
+// gU [16][KD][Co][Ci] (summed partials, Winograd domain) -> gw [Co][Ci][KD][3][3] = G^T gU G,
+// G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ void wgrad_wino_finish(const float* __restrict__ gU, float* __restrict__ gw, int Co, int Ci, int KD) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Co * Ci * KD) return;
+    const int kd = idx % KD, ci = (idx / KD) % Ci, co = idx / (KD * Ci);
+    float u[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[i][j] = gU[((size_t)((i * 4 + j) * KD + kd) * Co + co) * Ci + ci];
+    float t[3][4];                                   // G^T u: rows a = 0..2
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+        t[1][j] = 0.5f * (u[1][j] - u[2][j]);
+        t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+    }
+    float* o = gw + (((size_t)co * Ci + ci) * KD + kd) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o[a * 3 + 0] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+        o[a * 3 + 1] = 0.5f * (t[a][1] - t[a][2]);
+        o[a * 3 + 2] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+    }
+}
+
 inline int wgrad_workers(int Ci, int Co, long long ntiles, int occ = 1) {
     const int ytiles = ((Ci + CT - 1) / CT) * ((Co + CT - 1) / CT);
     long long p = 256 * occ / ytiles;           // `occ` persistent workgroups per CU in total (3-D: 1, 2-D: 2)
@@ -311,6 +455,34 @@ int launch_wgrad(const float* x, const float* gy, float* gw, float* partial, int
     const int n = Co * Ci * Cfg::NTAPS;
     hipLaunchKernelGGL(wgrad_reduce, dim3((n + 31) / 32), dim3(256), 0, st, partial, gw, n, P * Cfg::KG);
     return ECM_LAUNCH_RESULT();
+}
+
+template <int TD, int TH, int KD>
+int launch_wgrad_wino(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int Co, int D, int H, int W,
+                      hipStream_t st) {
+    using Cfg = WgCfg<1, TD, TH, KD>;
+    const int tiles_d = (D + TD - 1) / TD, tiles_h = (H + TH - 1) / TH, tiles_w = (W + TWV - 1) / TWV;
+    const long long ntiles = (long long)B * tiles_d * tiles_h * tiles_w;
+    const int ci_tiles = (Ci + CT - 1) / CT, co_tiles = (Co + CT - 1) / CT;
+    const int P = wgrad_workers(Ci, Co, ntiles, KD == 3 ? 1 : 2);
+    auto kern = conv3d_wgrad_mfma<1, TD, TH, KD, 3, 3, 1, true>;
+    {
+        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int n = 16 * KD * Co * Ci;
+    float* partial = scratch;
+    float* gU = scratch + (size_t)P * n;
+    hipLaunchKernelGGL(kern, dim3(P, ci_tiles * co_tiles), dim3(256), Cfg::LDS_BYTES, st, x, gy, partial, B, Ci, Co, D, H,
+                       W, D, H, W, tiles_d, tiles_h, tiles_w, ci_tiles, 1, 1);
+    hipLaunchKernelGGL(wgrad_reduce, dim3((n + 31) / 32), dim3(256), 0, st, partial, gU, n, P);
+    hipLaunchKernelGGL(wgrad_wino_finish, dim3((Co * Ci * KD + 255) / 256), dim3(256), 0, st, gU, gw, Co, Ci, KD);
+    return ECM_LAUNCH_RESULT();
+}
+
+inline long long ntiles_wino(int B, int D, int H, int W, int kd) {
+    const int TD = kd == 3 ? 2 : 1, TH = kd == 3 ? 8 : 16;
+    return (long long)B * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TWV - 1) / TWV);
 }
 
 inline long long ntiles_for(int B, int D, int H, int W, int stride) {
@@ -373,4 +545,22 @@ extern "C" int ecm_conv2d_wgrad_ex(const float* x, const float* gy, float* gw, v
     WG2(1, 1, 2, 1, 8);
 #undef WG2
     return ECM_EUNSUP;
+}
+
+// ---- Winograd F(2x2,3x3) weight gradient of the stride-1 3x3x3 Conv3d (kd = 3) / 3x3 Conv2d (kd = 1, D = 1) ------------------
+extern "C" long long ecm_conv_wino_wgrad_scratch_bytes(int B, int Ci, int Co, int D, int H, int W, int kd) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0 || (kd != 1 && kd != 3)) return 0;
+    const long long P = wgrad_workers(Ci, Co, ntiles_wino(B, D, H, W, kd), kd == 3 ? 1 : 2);
+    return (P + 1) * 16LL * kd * Co * Ci * (long long)sizeof(float);
+}
+
+extern "C" int ecm_conv_wino_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B,
+                                   int Ci, int Co, int D, int H, int W, int kd, void* stream) {
+    ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0);
+    if ((kd != 1 && kd != 3) || (kd == 1 && D != 1)) return ECM_EUNSUP;
+    if ((long long)D * H * W * 4 * 32 >= 0x7fffffffLL || ntiles_wino(B, D, H, W, kd) >= 0x7fffffffLL) return ECM_EUNSUP;
+    if (scratch_bytes < ecm_conv_wino_wgrad_scratch_bytes(B, Ci, Co, D, H, W, kd)) return ECM_ESCRATCH;
+    hipStream_t st = ecm_stream(stream);
+    if (kd == 3) return launch_wgrad_wino<2, 8, 3>(x, gy, gw, static_cast<float*>(scratch), B, Ci, Co, D, H, W, st);
+    return launch_wgrad_wino<1, 16, 1>(x, gy, gw, static_cast<float*>(scratch), B, Ci, Co, 1, H, W, st);
 }

@@ -408,6 +408,7 @@ def _pack_deconv(w):
 import os as _os
 WINOGRAD = _os.environ.get("ECM_WINOGRAD", "1") != "0"
 WINO2D_MIN_CI = 64
+WINOGRAD_WGRAD = _os.environ.get("ECM_WINOGRAD_WGRAD", "1") != "0"
 
 
 def _wino_pack(w, kd, flip_transpose):
@@ -447,8 +448,21 @@ def _deconv_fwd(x, packed, Co, out_dhw):
     return y
 
 
+def _wino_wgrad(x, gy, Co, Ci, kd):
+    """Winograd-form weight gradient of a stride-1 3x3(x3) convolution: x [B,Ci,(D,)H,W], gy [B,Co,(D,)H,W]."""
+    B = x.shape[0]
+    D, H, W = (x.shape[2:] if kd == 3 else (1,) + tuple(x.shape[2:]))
+    gw = torch.empty((Co, Ci) + ((3, 3, 3) if kd == 3 else (3, 3)), device=x.device, dtype=x.dtype)
+    nb = _lib.query("ecm_conv_wino_wgrad_scratch_bytes", B, Ci, Co, D, H, W, kd)
+    scratch = _scratch(nb, x.device)
+    _lib.call("ecm_conv_wino_wgrad", _p(x), _p(gy), _p(gw), _p(scratch), C.c_longlong(nb), B, Ci, Co, D, H, W, kd, _stream())
+    return gw
+
+
 def _wgrad(x, gy, Co, Ci, stride):
     """gw[Co,Ci,3,3,3] = sum gy[b,co,o] x[b,ci,o*stride+k-1]."""
+    if stride == 1 and WINOGRAD and WINOGRAD_WGRAD:
+        return _wino_wgrad(x, gy, Co, Ci, 3)
     B, _, D, H, W = x.shape
     gw = torch.empty(Co, Ci, 3, 3, 3, device=x.device, dtype=x.dtype)
     nb = _lib.query("ecm_conv3d_wgrad_scratch_bytes", B, Ci, Co, D, H, W, stride)
@@ -594,6 +608,7 @@ class Conv2dG(torch.autograd.Function):
         # Winograd where it is ahead of the direct kernel (tools/wino_time.py): from 64 input channels up -- with 32 the
         # per-tile transform + exchange costs as much as the multiplies it saves
         ctx.wino_f, ctx.wino_b = WINOGRAD and same and Ci >= WINO2D_MIN_CI, WINOGRAD and same and Co >= WINO2D_MIN_CI
+        ctx.wino_same = same
         if ctx.wino_f:
             y = _wino_run(x, _wino_pack(_c(w), 1, False), Co, 1)
         else:
@@ -634,7 +649,9 @@ class Conv2dG(torch.autograd.Function):
                 small = _conv2d_run(gy, _pack2d(w, True), Ci, 1, 1, 1, 1, 0, 0, Ho, Wo)
                 gx = torch.zeros(B, Ci, H, W, device=x.device, dtype=x.dtype)
                 gx[:, :, ::2, ::2] = small
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.wino_same and WINOGRAD and WINOGRAD_WGRAD:
+            gw = _wino_wgrad(x, gy, Co, Ci, 1)
+        elif ctx.needs_input_grad[1]:
             gw = _empty_like(w)
             nb = _lib.query("ecm_conv2d_wgrad_ex_scratch_bytes", B, Ci, Co, Ho, Wo, kh, kw, stride)
             scratch = _scratch(nb, x.device)

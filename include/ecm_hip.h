@@ -136,6 +136,13 @@ int ecm_conv_wino_pack_weight(const float* w, float* packed, int Co, int Ci, int
 int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int Ci, int Co, int D, int H, int W, int kd,
                       void* stream);
 
+/* Weight gradient of the same stride-1 convolutions in Winograd form: gw = G^T [ sum_tiles (A gy A^T) (.) (B^T x B) ] G, the
+ * per-lane operand transforms done on the fly from the raw LDS tiles of ecm_conv3d_k3_wgrad's kernel (conv3d_wgrad.hip).
+ * kd = 3: x [B,Ci,D,H,W], gy [B,Co,D,H,W] -> gw [Co,Ci,3,3,3];  kd = 1 (D = 1): gw [Co,Ci,3,3].  Deterministic. */
+long long ecm_conv_wino_wgrad_scratch_bytes(int B, int Ci, int Co, int D, int H, int W, int kd);
+int ecm_conv_wino_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B, int Ci,
+                        int Co, int D, int H, int W, int kd, void* stream);
+
 /* The classifier's last layer Conv3d(Ci<=32 -> 1) (cmfsm.py:624,629,634) on its own kernels: w is the reference weight
  * [1,Ci,3,3,3] (no packing); y: [B,1,D,H,W].  wgrad: gw [1,Ci,27] from x [B,Ci,D,H,W] and gy [B,1,D,H,W]. */
 int ecm_conv3d_c1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, void* stream);

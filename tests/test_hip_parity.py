@@ -736,3 +736,24 @@ def _winograd_conv2d_case(ecm, B, Ci, Co, H, W):
     close(y, ref, 1e-4, 2e-5)
     close(xg.grad, xs.grad, 1e-4, 2e-5)
     close(wg.grad, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,Ci,Co,dims", [(1, 32, 32, (4, 8, 16)), (2, 32, 32, (5, 7, 70)), (1, 64, 64, (3, 9, 33)), (1, 32, 64, (2, 4, 130)),
+                                          (1, 8, 12, (3, 5, 9)), (1, 64, 32, (6, 13, 65))])
+def test_winograd_wgrad3d_vs_torch(ecm, B, Ci, Co, dims):
+    """Weight gradient of nn.Conv3d(k 3, stride 1, pad 1) in Winograd form vs CPU autograd and vs the direct kernel."""
+    x, gy = seeded("ww.x", B, Ci, *dims), seeded("ww.g", B, Co, *dims)
+    ws = (seeded("ww.w", Co, Ci, 3, 3, 3) * 0.1).requires_grad_()
+    F.conv3d(x, ws, None, 1, 1).backward(gy)
+    got = ecm.ops._wino_wgrad(dev(x), dev(gy), Co, Ci, 3)
+    close(got, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 32, 32, 20, 64), (1, 64, 64, 33, 50), (1, 3, 32, 17, 37), (1, 128, 128, 9, 70), (2, 32, 480, 12, 40)])
+def test_winograd_wgrad2d_vs_torch(ecm, B, Ci, Co, H, W):
+    """Weight gradient of the encoder's 3x3 / stride 1 Conv2d in Winograd form vs CPU autograd."""
+    x, gy = seeded("ww2.x", B, Ci, H, W), seeded("ww2.g", B, Co, H, W)
+    ws = (seeded("ww2.w", Co, Ci, 3, 3) * 0.1).requires_grad_()
+    F.conv2d(x, ws, None, 1, 1).backward(gy)
+    got = ecm.ops._wino_wgrad(dev(x), dev(gy), Co, Ci, 1)
+    close(got, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))

@@ -378,7 +378,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 pm = json.load(f)
             if (H, W, D, B) == (576, 960, 192, 4):
-                traffic_conv = pm["conv3d_k3_mfma_32to32_B4"]["hbm_bytes_per_launch"]
+                traffic_conv = pm["conv_wino_mfma_32to32_B4" if ops.WINOGRAD and "conv_wino_mfma_32to32_B4" in pm
+                                  else "conv3d_k3_mfma_32to32_B4"]["hbm_bytes_per_launch"]
                 traffic_cv = pm["costvol_fwd_v4_B4"]["hbm_bytes_per_launch"]
                 traffic_note = pm.get("note", "rocprofv3 PMC, calibrated (profiles/r02_pmc_traffic.json)")
         except (OSError, KeyError, ValueError):
@@ -402,8 +403,7 @@ def main():
                          "note": "achieved counts the ALGORITHMIC (direct-convolution) FLOPs; the Winograd kernel executes 12/27 of "
                                  "them on the matrix cores (executed_*), which is how `frac` can exceed 1" if wino else
                                  "direct implicit GEMM: algorithmic == executed FLOPs",
-                         "traffic": traffic_conv if not wino else None,
-                         "traffic_note": traffic_note if not wino else "PMC pass on file is for the direct kernel (profiles/r02_pmc_traffic.json)",
+                         "traffic": traffic_conv, "traffic_note": traffic_note,
                          "launches_timed": len(sel), "avg_launch_ms": conv_ms,
                          "of_which_32to32": {"achieved": main_tf, "frac": main_tf / PEAK_F32_MFMA_TFLOPS,
                                              "avg_launch_ms": main_ms, "launches_timed": len(main_l)}},

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wgrad|gn|costvol] [B]"""
+"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wino|wgrad|wino_wgrad|gn|costvol] [B]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,8 +12,16 @@ if which == "conv":
     x = torch.randn(B, 32, 48, 144, 240, device=dev); w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
     pk = ops._pack_conv(w)
     for _ in range(5): y = ops._conv_fwd(x, pk, 32, 1)
+elif which == "wino":
+    x = torch.randn(B, 32, 48, 144, 240, device=dev); w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
+    pk = ops._wino_pack(w, 3, False)
+    for _ in range(5): y = ops._wino_run(x, pk, 32, 3)
+elif which == "wino_wgrad":
+    x = torch.randn(B, 32, 48, 144, 240, device=dev); gy = torch.randn(B, 32, 48, 144, 240, device=dev)
+    for _ in range(5): g = ops._wino_wgrad(x, gy, 32, 32, 3)
 elif which == "wgrad":
     x = torch.randn(B, 32, 48, 144, 240, device=dev); gy = torch.randn(B, 32, 48, 144, 240, device=dev)
+    ops.WINOGRAD_WGRAD = False
     for _ in range(5): g = ops._wgrad(x, gy, 32, 32, 1)
 elif which == "gn":
     x = torch.randn(B, 32, 48, 144, 240, device=dev, requires_grad=True)

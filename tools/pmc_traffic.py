@@ -5,7 +5,8 @@ Passes (each its own run, `--kernel-trace --pmc <one counter>` only, as MI355X_M
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d D/calib_fetch -- tools/micro/fetch_calib
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d D/calib_write -- tools/micro/fetch_calib
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d D/conv_fetch  -- python3 tools/conv_only.py conv 4
-    ... WRITE_SIZE -> D/conv_write;  the same for `costvol 4` -> D/cv_fetch, D/cv_write
+    ... WRITE_SIZE -> D/conv_write;  the same for `costvol 4` -> D/cv_fetch, D/cv_write, `wino 4` -> D/wino_fetch, D/wino_write
+    and `wino_wgrad 4` -> D/ww_fetch, D/ww_write
 usage: pmc_traffic.py D > profiles/r02_pmc_traffic.json
 
 Calibration: tools/micro/fetch_calib streams a known byte count once from a 1 GiB buffer with each access shape; factor =
@@ -63,6 +64,10 @@ def main():
     wf = fac.get("write_b128", 1.0)
     for key, sub, dirs, ffac, alg in (
             ("conv3d_k3_mfma_32to32_B4", "conv3d_k3_mfma", ("conv_fetch", "conv_write"), fac.get("read_b32_rows", 1.0),
+             2 * 4 * 32 * 48 * 144 * 240 * 4),
+            ("conv_wino_mfma_32to32_B4", "conv_wino_mfma", ("wino_fetch", "wino_write"), fac.get("read_b32_rows", 1.0),
+             2 * 4 * 32 * 48 * 144 * 240 * 4),
+            ("conv3d_wgrad_wino_32to32_B4", "conv3d_wgrad_mfma", ("ww_fetch", "ww_write"), fac.get("read_b32_rows", 1.0),
              2 * 4 * 32 * 48 * 144 * 240 * 4),
             ("costvol_fwd_v4_B4", "costvol_fwd", ("cv_fetch", "cv_write"), fac.get("read_b128_global", 2.0),
              4 * (2 * 32 * 48 * 144 * 240 + 2 * 32 * 144 * 240) * 4)):

@@ -557,10 +557,10 @@ extern "C" long long ecm_conv_wino_wgrad_scratch_bytes(int B, int Ci, int Co, in
 extern "C" int ecm_conv_wino_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B,
                                    int Ci, int Co, int D, int H, int W, int kd, void* stream) {
     ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0);
-    if ((kd != 1 && kd != 3) || (kd == 1 && D != 1)) return ECM_EUNSUP;
+    if (kd != 1 && kd != 3) return ECM_EUNSUP;
     if ((long long)D * H * W * 4 * 32 >= 0x7fffffffLL || ntiles_wino(B, D, H, W, kd) >= 0x7fffffffLL) return ECM_EUNSUP;
     if (scratch_bytes < ecm_conv_wino_wgrad_scratch_bytes(B, Ci, Co, D, H, W, kd)) return ECM_ESCRATCH;
     hipStream_t st = ecm_stream(stream);
     if (kd == 3) return launch_wgrad_wino<2, 8, 3>(x, gy, gw, static_cast<float*>(scratch), B, Ci, Co, D, H, W, st);
-    return launch_wgrad_wino<1, 16, 1>(x, gy, gw, static_cast<float*>(scratch), B, Ci, Co, 1, H, W, st);
+    return launch_wgrad_wino<1, 16, 1>(x, gy, gw, static_cast<float*>(scratch), B, Ci, Co, D, H, W, st);   // D independent planes
 }

@@ -363,6 +363,6 @@ extern "C" int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y,
     ECM_CHECK_ARG(x && upacked && y && B > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0);
     hipStream_t st = ecm_stream(stream);
     if (kd == 3) return launch_wino<3, 2, 1, WINO_CIC3>(x, upacked, y, B, Ci, Co, D, H, W, st);
-    if (kd == 1 && D == 1) return launch_wino<1, 1, 2, WINO_CIC2>(x, upacked, y, B, Ci, Co, 1, H, W, st);
+    if (kd == 1) return launch_wino<1, 1, 2, WINO_CIC2>(x, upacked, y, B, Ci, Co, D, H, W, st);   // D independent planes
     return ECM_EUNSUP;
 }

@@ -74,6 +74,8 @@ class EncConv2d(nn.Conv2d):
                 and self.padding_mode == "zeros" and ops.conv2d_supported(self.in_channels, self.out_channels, kh, kw, s, d))
 
     def forward(self, x):
+        if x.dim() == 5:       # [B,C,d*d,H/d,W/d]: the phase planes of a dilation-d layer (feature_extraction._run_layer)
+            return ops.conv2d_planes(x, self.weight)
         if self._native():
             return ops.conv2d(x, self.weight, self.stride[0], self.dilation[0])      # raises on CPU tensors, like every op
         return super().forward(x)
@@ -266,15 +268,27 @@ class feature_extraction(nn.Module):
         layers += [block(self.inplanes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
+    @staticmethod
+    def _run_layer(layer, x):
+        """One residual stage.  If every convolution in it is a 3x3 / stride 1 layer of the same dilation d > 1 (cmfsm's
+        layer4, cmfsm.py:150), run it on d*d phase planes, where the convolutions are ordinary 3x3 ones (ops.phase_split)."""
+        convs = [m for m in layer.modules() if isinstance(m, nn.Conv2d)]
+        d = convs[0].dilation[0]
+        ok = (ops.WINOGRAD and d > 1 and x.shape[-2] % d == 0 and x.shape[-1] % d == 0
+              and all(m.kernel_size == (3, 3) and m.stride == (1, 1) and m.dilation == (d, d) and m.padding == (d, d) for m in convs))
+        if not ok:
+            return layer(x)
+        return ops.phase_merge(layer(ops.phase_split(x, d)), d)
+
     def forward(self, x):
         output_all = _seq_fused(self.firstconv, x)
         output_rt = self.layer1(_seq_fused(self.secondconv, output_all))
         output_raw = self.layer2(output_rt)
         if self._raw_is_layer3:                       # cmfsm_sub_16.py:205-207
-            output_raw = self.layer3(output_raw)
-            output_skip = self.layer4(output_raw)
+            output_raw = self._run_layer(self.layer3, output_raw)
+            output_skip = self._run_layer(self.layer4, output_raw)
         else:
-            output_skip = self.layer4(self.layer3(output_raw))
+            output_skip = self._run_layer(self.layer4, self._run_layer(self.layer3, output_raw))
         size = output_skip.shape[-2:]
         pooled = _pyramid_pools(output_skip, [getattr(self, f"branch{i}")[0] for i in (1, 2, 3, 4)])
         pyramid = [bilinear_upsample(_seq_fused(getattr(self, f"branch{i}"), pooled[i - 1], start=1), size) for i in (4, 3, 2, 1)]

@@ -424,9 +424,9 @@ def _wino_pack(w, kd, flip_transpose):
 
 
 def _wino_run(x, packed, Co, kd):
-    """x: [B,Ci,D,H,W] (kd 3) or [B,Ci,H,W] (kd 1) -> same spatial shape with Co channels."""
+    """x: [B,Ci,D,H,W] (kd 3; or kd 1 on D independent planes) or [B,Ci,H,W] (kd 1) -> same spatial shape with Co channels."""
     B, Ci = x.shape[:2]
-    D, H, W = (x.shape[2:] if kd == 3 else (1,) + tuple(x.shape[2:]))
+    D, H, W = (x.shape[2:] if x.dim() == 5 else (1,) + tuple(x.shape[2:]))
     y = torch.empty((B, Co) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
     _lib.call("ecm_conv_wino_fwd", _p(x), _p(packed), _p(y), B, Ci, Co, D, H, W, kd, _stream())
     return y
@@ -451,7 +451,7 @@ def _deconv_fwd(x, packed, Co, out_dhw):
 def _wino_wgrad(x, gy, Co, Ci, kd):
     """Winograd-form weight gradient of a stride-1 3x3(x3) convolution: x [B,Ci,(D,)H,W], gy [B,Co,(D,)H,W]."""
     B = x.shape[0]
-    D, H, W = (x.shape[2:] if kd == 3 else (1,) + tuple(x.shape[2:]))
+    D, H, W = (x.shape[2:] if x.dim() == 5 else (1,) + tuple(x.shape[2:]))
     gw = torch.empty((Co, Ci) + ((3, 3, 3) if kd == 3 else (3, 3)), device=x.device, dtype=x.dtype)
     nb = _lib.query("ecm_conv_wino_wgrad_scratch_bytes", B, Ci, Co, D, H, W, kd)
     scratch = _scratch(nb, x.device)
@@ -676,6 +676,46 @@ def conv2d(x, w, stride=1, dil=1, pad_top=None, pad_left=None, Ho=None, Wo=None)
 def conv2d_k3(x, w):
     """3x3 / stride 1 / pad 1 (kept as the name the 32/64-channel encoder layers were introduced under)."""
     return conv2d(x, w, 1, 1)
+
+
+# ---- dilated 3x3 layers as d*d independent phase planes ---------------------------------------------------------------------
+# A dilation-d 3x3 convolution (padding d) touches only pixels of equal (y mod d, x mod d): it is d*d independent ordinary
+# 3x3 / pad 1 convolutions of the phase sub-images x[..., p::d, q::d].  A layer whose convolutions all have dilation d
+# (cmfsm's layer4, cmfsm.py:150: 128 -> 128, dilation 2) therefore runs on the Winograd kernels with its activations kept as
+# [B,C,d*d,H/d,W/d] (GroupNorm and the residual adds see the same elements in another order), at the price of one
+# re-arrangement on the way in and one on the way out.
+def phase_split(x, d):
+    B, Cc, H, W = x.shape
+    return x.view(B, Cc, H // d, d, W // d, d).permute(0, 1, 3, 5, 2, 4).reshape(B, Cc, d * d, H // d, W // d)
+
+
+def phase_merge(x, d):
+    B, Cc, _, h, w = x.shape
+    return x.view(B, Cc, d, d, h, w).permute(0, 1, 4, 2, 5, 3).reshape(B, Cc, h * d, w * d)
+
+
+class Conv2dPlanes(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 Conv2d applied to every plane of x [B,Ci,P,h,w] (P = the phase planes of a dilated layer) on
+    the Winograd kernels: forward, data gradient and weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _chk(x, w)
+        x, w = _c(x), _c(w)
+        ctx.save_for_backward(x, w)
+        return _wino_run(x, _wino_pack(w, 1, False), w.shape[0], 1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _c(gy)
+        gx = _wino_run(gy, _wino_pack(w, 1, True), w.shape[1], 1) if ctx.needs_input_grad[0] else None
+        gw = _wino_wgrad(x, gy, w.shape[0], w.shape[1], 1) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def conv2d_planes(x, w):
+    return Conv2dPlanes.apply(x, w)
 
 
 def conv3d_k3(x, w, stride=1):

@@ -127,7 +127,8 @@ int ecm_conv3d_k3_fwd(const float* x, const float* wpacked, float* y,
 
 /* The same stride-1 convolution by Winograd F(2x2,3x3) in the (h,w) plane, direct along depth (conv_wino.hip): 2.25x fewer
  * multiplies, fp32 throughout (transforms add/subtract/halve only; results differ from the direct kernel by fp32 rounding).
- * kd = 3: Conv3d 3x3x3, x [B,Ci,D,H,W] -> y [B,Co,D,H,W];  kd = 1: Conv2d 3x3 (pass D = 1).  Any Ci, Co (32 output
+ * kd = 3: Conv3d 3x3x3, x [B,Ci,D,H,W] -> y [B,Co,D,H,W];  kd = 1: Conv2d 3x3 applied to each of the D planes (D = 1 for
+ * a plain image; D = d*d phase planes of a dilation-d layer, see models.feature_extraction).  Any Ci, Co (32 output
  * channels per workgroup; more go to a second grid dimension).  Weights: reference layout [Co,Ci,kd,3,3], transformed and
  * packed by ecm_conv_wino_pack_weight (flip_transpose != 0: the data-gradient operator, Cin' = Co, Cout' = Ci; size query
  * with the swapped counts). */
@@ -138,7 +139,7 @@ int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int
 
 /* Weight gradient of the same stride-1 convolutions in Winograd form: gw = G^T [ sum_tiles (A gy A^T) (.) (B^T x B) ] G, the
  * per-lane operand transforms done on the fly from the raw LDS tiles of ecm_conv3d_k3_wgrad's kernel (conv3d_wgrad.hip).
- * kd = 3: x [B,Ci,D,H,W], gy [B,Co,D,H,W] -> gw [Co,Ci,3,3,3];  kd = 1 (D = 1): gw [Co,Ci,3,3].  Deterministic. */
+ * kd = 3: x [B,Ci,D,H,W], gy [B,Co,D,H,W] -> gw [Co,Ci,3,3,3];  kd = 1 (D independent planes): gw [Co,Ci,3,3].  Deterministic. */
 long long ecm_conv_wino_wgrad_scratch_bytes(int B, int Ci, int Co, int D, int H, int W, int kd);
 int ecm_conv_wino_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B, int Ci,
                         int Co, int D, int H, int W, int kd, void* stream);

@@ -757,3 +757,21 @@ def test_winograd_wgrad2d_vs_torch(ecm, B, Ci, Co, H, W):
     F.conv2d(x, ws, None, 1, 1).backward(gy)
     got = ecm.ops._wino_wgrad(dev(x), dev(gy), Co, Ci, 1)
     close(got, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,H,W,d", [(2, 128, 24, 40, 2), (1, 64, 16, 36, 2), (1, 128, 16, 32, 4)])
+def test_dilated_layer_as_phase_planes(ecm, B, C, H, W, d):
+    """A dilation-d 3x3 convolution (feature_extraction layer4, cmfsm.py:150) run as d*d phase planes on the Winograd
+    kernels (ops.phase_split / conv2d_planes / phase_merge): forward and both gradients vs CPU F.conv2d with dilation."""
+    x = seeded("ph.x", B, C, H, W)
+    w = seeded("ph.w", C, C, 3, 3) * (2.0 / (9 * C)) ** 0.5
+    xs, ws = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = F.conv2d(xs, ws, None, 1, d, d)
+    G = seeded("ph.G", *ref.shape)
+    ref.backward(G)
+    xg, wg = dev(x).requires_grad_(), dev(w).requires_grad_()
+    y = ecm.ops.phase_merge(ecm.ops.conv2d_planes(ecm.ops.phase_split(xg, d), wg), d)
+    y.backward(dev(G))
+    close(y, ref, 1e-4, 2e-5)
+    close(xg.grad, xs.grad, 1e-4, 2e-5)
+    close(wg.grad, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))

@@ -12,11 +12,15 @@
 //   B = V_xi : lane l holds V[k = l>>5][tile column t = l&31] (LDS image [xi][ci][plane][tile row][32], double buffered)
 // One workgroup (4 waves) owns TD planes x TR tile rows x 32 tile columns of 2x2 tiles (TD x 2TR x 64 outputs) for 32
 // output channels; wave w owns the frequencies 4w..4w+3 (4 x TD*TR accumulators of 16 registers).  Per chunk of CIC input
-// channels every thread transforms ONE 4x4 input patch (16 buffer loads with hardware zero padding -> 32 adds -> 16 LDS
-// stores), prefetched one chunk ahead through registers, while the previous chunk's MFMAs run; one barrier per chunk; two
-// workgroups per CU so that one's transform / barrier sits under the other's matrix work.  Epilogue: the column half of
-// A^T M A in registers (a wave owns one frequency row), the row half after an exchange through LDS.
+// channels every thread transforms ONE 4x4 input patch (8 eight-byte buffer loads, contiguous across the lanes, with hardware
+// zero padding -> 32 adds -> 16 LDS stores), prefetched TWO chunks ahead through registers while the previous chunks' MFMAs
+// run; one barrier per chunk; two workgroups per CU so that one's transform / barrier sits under the other's matrix work.
+// The patch loads are inline asm with hand-counted s_waitcnt (the compiler would drain the queue at every transform, and its
+// raw_buffer_load_b64 builtin is lowered to a one-dword load): tools/check_wino_isa.py proves on the built code object that
+// no register is touched while its load is in flight.  Epilogue: the column half of A^T M A in registers (a wave owns one
+// frequency row), the row half after an exchange through LDS.
 #include "common.h"
+#include <type_traits>
 
 #ifdef WINO_PROFILE
 __device__ unsigned long long wino_prof[4 * 8];   // [wave][phase] cycles of one workgroup; debugging aid (tools/micro/wino_prof.hip)
@@ -69,19 +73,26 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     const int pc = rest / (NP * TR);                         // wave-uniform (static_assert above)
     const int pz = (rest / TR) % NP, pr = rest % TR;
     const size_t HWi = (size_t)H * W, DHWi = (size_t)D * HWi;
-    unsigned poff[16];
+    // The 4x4 patch is fetched as 8 pairs of neighbouring columns (8-byte loads, contiguous across the lanes): pair A =
+    // columns (ow-1, ow), pair B = (ow+1, ow+2) of rows oh-1..oh+2.  Rows / planes outside the volume get the out-of-range
+    // offset (hardware zero fill).  A pair never straddles the end of a row: at the left border pair A is read one column to
+    // the right, at the right border pair B one column to the left, and `fix_edges` moves the values into place.
+    unsigned poff[8];
+    const int ow_t = ow0 + 2 * l31;                          // first output column of this thread's tile
+    const bool edge_l = ow_t == 0, edge_r = ow_t + 2 >= W && ow_t + 1 < W;
     {
         const int gz = od0 - KD / 2 + pz;
-        const int gy0 = oh0 - 1 + 2 * pr, gx0 = ow0 - 1 + 2 * l31;
+        const int gy0 = oh0 - 1 + 2 * pr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gy = gy0 + i, gx = gx0 + j;
-                const bool ok = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                poff[i * 4 + j] = ok ? (unsigned)(gz * (int)HWi + gy * W + gx) * 4u : 0x80000000u;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int gy = gy0 + i;
+            const bool ok = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H;
+            const int row = gz * (int)HWi + gy * W;
+            poff[i * 2 + 0] = ok && ow_t < W ? (unsigned)(row + ow_t - 1 + (edge_l ? 1 : 0)) * 4u : 0x80000000u;
+            poff[i * 2 + 1] = ok && ow_t + 1 < W ? (unsigned)(row + ow_t + 1 - (edge_r ? 1 : 0)) * 4u : 0x80000000u;
+        }
     }
+    const bool wg_edge = ow0 == 0 || ow0 + 66 > W;          // some tile of this workgroup touches a row end (uniform)
     const float* xb = x + (size_t)b * Ci * DHWi;
     const unsigned plane_bytes = (unsigned)DHWi * 4u;
     const int pc_u = __builtin_amdgcn_readfirstlane(pc);
@@ -90,34 +101,69 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-    constexpr int NUQ = (UF / 4 + 255) / 256;                // weight float4s per thread per chunk
-    static_assert(UF % 4 == 0, "weight chunk moves as float4");
+    constexpr int NUQ = UF / 4 / 256;                        // weight float4s per thread per chunk
+    static_assert(UF % (4 * 256) == 0, "weight chunk moves as whole float4 rounds of the workgroup (hand-counted vmcnt)");
 
     // Patches are fetched TWO chunks ahead of their transform (two register buffers, used alternately by even / odd chunks):
-    // the 16 loads then have a whole chunk's worth of MFMAs to land, so the transform never waits for memory.
-    float rawA[16], rawB[16];
-    auto load_raw = [&](int chunk, float (&raw)[16]) {
+    // the 8 loads then have a whole chunk's worth of MFMAs to land, so the transform never waits for memory.
+    // The loads are issued through inline asm with hand-counted waits: the compiler cannot count VMEM operations around the
+    // loop and would drain the queue (s_waitcnt vmcnt(0)) before every transform -- waiting for the patch issued a moment
+    // ago instead of the one issued two chunks ago.  (Loads it does not know of only make ITS waits stricter, never unsafe.)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 rawA[8], rawB[8];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto load_raw = [&](int chunk, f32x2 (&raw)[8]) {
         const int c = chunk * CIC + pc_u;
         const bool live = c < Ci;                            // channel padding: an empty descriptor reads zeros
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(live ? c : 0) * DHWi), 0,
-                                                            live ? plane_bytes : 0u, 0x00020000);
+        const unsigned long long base = reinterpret_cast<unsigned long long>(xb + (size_t)(live ? c : 0) * DHWi);
+        u32x4 rsrc;
+        rsrc.x = __builtin_amdgcn_readfirstlane((unsigned)base);
+        rsrc.y = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
+        rsrc.z = live ? plane_bytes : 0u;
+        rsrc.w = 0x00020000u;
+        // s_nop: the descriptor may have been written by v_readfirstlane a moment ago (VALU-writes-SGPR -> VMEM needs 5 wait
+        // states, and the hazard recogniser does not look into asm)
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(raw[0]) : "v"(poff[0]), "s"(rsrc) : "memory");
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            raw[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, poff[k], 0, 0));
+        for (int k = 1; k < 8; ++k)
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(raw[k]) : "v"(poff[k]), "s"(rsrc) : "memory");
+    };
+    // A patch has landed when at most N VMEM operations issued after it are outstanding.  The compiler believes the asm
+    // outputs valid from the moment of issue, so every use must be ordered behind the wait by hand: the empty asm statements
+    // (volatile, hence after the wait) redefine the registers in place and all uses hang off them.  That it also inserted no
+    // copies in between is checked in the disassembly of the built library (tools/check_wino_isa.py, run by tests/test_abi.py).
+    auto wait_raw = [&](f32x2 (&raw)[8], auto n) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n)::value) : "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(raw[k]));
     };
     auto dma_u = [&](int chunk, float* dst) {
         const float* src = ug + (size_t)chunk * UF;
 #pragma unroll
-        for (int i = 0; i < NUQ; ++i) {
-            const int e = tid + i * 256;
-            if (e < UF / 4)
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)e * 4), (lds_ptr_t)(dst + (wave_u * 64 + i * 256) * 4), 16, 0, 0);
-        }
+        for (int i = 0; i < NUQ; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)(tid + i * 256) * 4),
+                                             (lds_ptr_t)(dst + (wave_u * 64 + i * 256) * 4), 16, 0, 0);
     };
     // V = B^T d B of the patch in `raw` -> Vs image `dst`: 16 frequency planes, this thread's (pc, pz, pr, t) slot.
     // Two halves so that each fits into the shadow of one group of MFMAs in the main loop.
     float tmp[16];
-    auto transform_rows = [&](const float (&raw)[16]) {
+    auto transform_rows = [&](const f32x2 (&rawp)[8]) {
+        float raw[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            raw[i * 4 + 0] = rawp[i * 2].x; raw[i * 4 + 1] = rawp[i * 2].y;
+            raw[i * 4 + 2] = rawp[i * 2 + 1].x; raw[i * 4 + 3] = rawp[i * 2 + 1].y;
+        }
+        if (wg_edge) {                                       // pairs read shifted at a row end: move into place, zero the pad
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a0 = raw[i * 4], a1 = raw[i * 4 + 1], b0 = raw[i * 4 + 2], b1 = raw[i * 4 + 3];
+                raw[i * 4 + 0] = edge_l ? 0.f : a0;
+                raw[i * 4 + 1] = edge_l ? a0 : a1;
+                raw[i * 4 + 2] = edge_r ? b1 : b0;
+                raw[i * 4 + 3] = edge_r ? 0.f : b1;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                        // rows: B^T d
             const float d0 = raw[j], d1 = raw[4 + j], d2 = raw[8 + j], d3 = raw[12 + j];
@@ -149,32 +195,29 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
 #endif
     // ---- prologue: chunk 0 into buffer 0, chunk 1's patch into registers -------------------------------------------------
     // chunk c's patch lives in rawA for even c, rawB for odd c
+    // Patch loads are issued for every chunk index up to nchunks + 2 -- beyond the last chunk through an empty descriptor,
+    // which costs no memory access -- so that every wait below is a constant count.
     load_raw(0, rawA);
     dma_u(0, Us);
-    if (nchunks > 1) load_raw(1, rawB);
-    if (nchunks > 2) {
-        // chunk 0's patch (the oldest 16 loads) is needed now; chunk 1's may stay in flight
-        transform_rows(rawA);                                // the compiler waits for exactly the loads it reads
-        transform_cols_store(Vs);
-        load_raw(2, rawA);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // DMA of chunk 0 (older than chunk 2's 16 loads) has landed
-    } else {
-        transform_rows(rawA);
-        transform_cols_store(Vs);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    load_raw(1, rawB);
+    wait_raw(rawA, std::integral_constant<int, NUQ + 8>{});   // younger than chunk 0's patch: its weights, chunk 1's patch
+    transform_rows(rawA);
+    transform_cols_store(Vs);
+    load_raw(2, rawA);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // chunk 1's patch and the weights of chunk 0 have landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // raw barrier: see the main loop
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     WN_T(0);
 
     // One chunk; PAR = c & 1 picks the register buffer that holds chunk c+1's patch (and receives chunk c+3's).
-    auto chunk_body = [&](int c, float (&raw_next)[16]) {
+    auto chunk_body = [&](int c, f32x2 (&raw_next)[8], auto last) {
+        constexpr bool LAST = decltype(last)::value;         // the odd chunk out at the end: nothing left to stage
         const int buf = c & 1;
         const float* Vc = Vs + buf * VF;
         const float* Uc = Us + buf * UF;
         float* Vn = Vs + (buf ^ 1) * VF;
-        const bool more = c + 1 < nchunks, more3 = c + 3 < nchunks;
+        const bool more = !LAST && c + 1 < nchunks;
         // (1) MFMA operands of this chunk into registers: frequency 0 first, so that its MFMAs can start as soon as ITS reads
         //     are back while the other three groups' reads are still in flight
         float av[4][CIC / 2][KD], bw[4][CIC / 2][NP][TR];
@@ -209,29 +252,43 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
                         for (int r = 0; r < TR; ++r)
                             acc[f][p * TR + r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f][kk][kd], bw[f][kk][p + kd][r],
                                                                                       acc[f][p * TR + r], 0, 0, 0);
-            if (f == 0 && more) transform_rows(raw_next);                 // chunk c+1's patch: loaded two chunks ago
+            if (f == 0 && more) {                                          // chunk c+1's patch: loaded two chunks ago;
+                wait_raw(raw_next, std::integral_constant<int, NUQ + 8>{});   // younger: weights of chunk c, patch of c+2
+                transform_rows(raw_next);
+            }
             if (f == 1 && more) transform_cols_store(Vn);
-            if (f == 2 && more) dma_u(c + 1, Us + (buf ^ 1) * UF);
-            if (f == 3 && more3) load_raw(c + 3, raw_next);               // the buffer just consumed gets chunk c+3's patch
+            // DMA and patch loads are unconditional (past the end: the last chunk's weights again into the buffer nobody
+            // reads, patches through an empty descriptor), so that every wait is a constant count on every path
+            if (f == 2 && !LAST) dma_u(more ? c + 1 : c, Us + (buf ^ 1) * UF);
+            if (f == 3 && !LAST) load_raw(c + 3, raw_next);               // the buffer just consumed gets chunk c+3's patch
             __builtin_amdgcn_sched_barrier(0);
         }
         WN_T(2);
-        // weight DMA of chunk c+1 landed: the only VMEM operations younger than it are the 16 patch loads of chunk c+3
+        // weight DMA of chunk c+1 landed: the only VMEM operations younger than it are the 8 patch loads of chunk c+3
         // (chunk c+2's, issued one chunk earlier, are older and are waited for with it -- they have had a full chunk)
-        if (more3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!LAST) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         WN_T(3);
-        // NOT __syncthreads(): its workgroup fence waits vmcnt(0), i.e. for the 16 patch loads issued a moment ago -- a full
+        // NOT __syncthreads(): its workgroup fence waits vmcnt(0), i.e. for the 8 patch loads issued a moment ago -- a full
         // memory round trip per chunk.  Own LDS writes done + raw barrier is all the hand-off of V / U needs.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         WN_T(4);
     };
-    for (int c = 0; c < nchunks; c += 2) {
-        chunk_body(c, rawB);                                 // chunk c even: chunk c+1's patch is in rawB
-        if (c + 1 < nchunks) chunk_body(c + 1, rawA);
+    {
+        int c = 0;
+        for (; c + 1 < nchunks; c += 2) {
+            chunk_body(c, rawB, std::false_type{});          // chunk c even: chunk c+1's patch is in rawB
+            chunk_body(c + 1, rawA, std::false_type{});
+        }
+        if (c < nchunks) chunk_body(c, rawB, std::true_type{});
     }
+
+    // The patch loads issued past the last chunk (empty descriptor) still write their registers when they return: keep both
+    // buffers allocated until the queue has drained, or the register allocator hands them to the epilogue early.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(rawA[k]), "v"(rawB[k]));
 
     // ---- epilogue: Y = A^T M A.  Wave w owns frequency ROW i = w (xi = 4w + j), so the column half of the transform,
     // T[i][b] = sum_j M[i][j] A[j][b], is done in registers; only T (2 of 4 values) crosses the waves through LDS:
@@ -361,6 +418,7 @@ extern "C" int ecm_conv_wino_pack_weight(const float* w, float* packed, int Co, 
 extern "C" int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int Ci, int Co, int D, int H, int W,
                                  int kd, void* stream) {
     ECM_CHECK_ARG(x && upacked && y && B > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0);
+    if (W < 2) return ECM_EUNSUP;                            // patches are read as pairs of neighbouring columns
     hipStream_t st = ecm_stream(stream);
     if (kd == 3) return launch_wino<3, 2, 1, WINO_CIC3>(x, upacked, y, B, Ci, Co, D, H, W, st);
     if (kd == 1) return launch_wino<1, 1, 2, WINO_CIC2>(x, upacked, y, B, Ci, Co, D, H, W, st);   // D independent planes

@@ -408,6 +408,11 @@ def _pack_deconv(w):
 import os as _os
 WINOGRAD = _os.environ.get("ECM_WINOGRAD", "1") != "0"
 WINO2D_MIN_CI = 64
+
+
+def _wino_ok(x):
+    """Winograd kernels read the patch as pairs of neighbouring columns: rows of at least two elements."""
+    return WINOGRAD and x.shape[-1] >= 2
 WINOGRAD_WGRAD = _os.environ.get("ECM_WINOGRAD_WGRAD", "1") != "0"
 
 
@@ -483,7 +488,7 @@ class Conv3dK3(torch.autograd.Function):
             B, Ci, D, H, W = x.shape
             y = torch.empty(B, 1, D, H, W, device=x.device, dtype=x.dtype)
             _lib.call("ecm_conv3d_c1_fwd", _p(x), _p(w), _p(y), B, Ci, D, H, W, _stream())
-        elif stride == 1 and WINOGRAD:
+        elif stride == 1 and _wino_ok(x):
             y = _wino_run(x, _wino_pack(w, 3, False), w.shape[0], 3)
         else:
             y = _conv_fwd(x, _pack_conv(w), w.shape[0], stride)
@@ -502,7 +507,7 @@ class Conv3dK3(torch.autograd.Function):
                 gx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
                 _lib.call("ecm_conv3d_c1_dgrad", _p(gy), _p(w), _p(gx), x.shape[0], Ci, x.shape[2], x.shape[3], x.shape[4],
                           _stream())
-            elif ctx.stride == 1 and WINOGRAD:
+            elif ctx.stride == 1 and _wino_ok(x):
                 gx = _wino_run(gy, _wino_pack(w, 3, True), Ci, 3)
             elif ctx.stride == 1:
                 gx = _conv_fwd(gy, _pack_conv(w, True), Ci, 1)
@@ -607,7 +612,7 @@ class Conv2dG(torch.autograd.Function):
         same = (kh, kw, stride, dil, pad_top, pad_left) == (3, 3, 1, 1, 1, 1) and (Ho, Wo) == tuple(x.shape[-2:])
         # Winograd where it is ahead of the direct kernel (tools/wino_time.py): from 64 input channels up -- with 32 the
         # per-tile transform + exchange costs as much as the multiplies it saves
-        ctx.wino_f, ctx.wino_b = WINOGRAD and same and Ci >= WINO2D_MIN_CI, WINOGRAD and same and Co >= WINO2D_MIN_CI
+        ctx.wino_f, ctx.wino_b = _wino_ok(x) and same and Ci >= WINO2D_MIN_CI, _wino_ok(x) and same and Co >= WINO2D_MIN_CI
         ctx.wino_same = same
         if ctx.wino_f:
             y = _wino_run(x, _wino_pack(_c(w), 1, False), Co, 1)

@@ -80,3 +80,18 @@ def test_state_dict_contract_on_cpu(cmfsm_shapes):
     assert list(sd.keys()) == list(cmfsm_shapes.keys())
     assert all(list(sd[k].shape) == cmfsm_shapes[k] for k in sd)
     assert sum(v.numel() for v in sd.values()) == 5255368
+
+
+def test_wino_asm_loads_not_read_early():
+    """csrc/conv_wino.hip issues its patch loads as inline asm with hand-counted s_waitcnt: prove on the built code object
+    that no instruction touches a load's destination register while the load may be in flight (tools/check_wino_isa.py)."""
+    import subprocess
+    import sys
+    so = os.path.join(ROOT, "explicit-context-mapping-for-stereo-matching_amd", "csrc", "libecm_hip.so")
+    tools = ("/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-objcopy", "/opt/rocm/lib/llvm/bin/clang-offload-bundler")
+    if not os.path.exists(so) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("needs the built library and the ROCm llvm binutils")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_wino_isa.py"), so], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 kernels checked, 0 problems" in r.stdout
+

@@ -682,7 +682,10 @@ def test_no_miopen_convolution_in_the_model(ecm):
 
 # ------------------------------------------------------------------ Winograd F(2x2,3x3) kernels (csrc/conv_wino.hip)
 @pytest.mark.parametrize("B,Ci,Co,dims", [(1, 32, 32, (4, 6, 64)), (2, 32, 32, (5, 7, 70)), (1, 64, 64, (3, 9, 33)), (1, 32, 64, (2, 4, 130)),
-                                          (1, 8, 12, (3, 5, 9)), (1, 32, 32, (1, 1, 1)), (1, 64, 32, (6, 13, 65))])
+                                          (1, 8, 12, (3, 5, 9)), (1, 32, 32, (1, 1, 1)), (1, 64, 32, (6, 13, 65)),
+                                          # row ends: the patch is read as column pairs, shifted at either border
+                                          (1, 4, 4, (2, 3, 2)), (1, 8, 8, (2, 5, 3)), (1, 16, 16, (2, 3, 65)), (1, 32, 32, (2, 4, 66)),
+                                          (1, 16, 16, (1, 3, 127)), (1, 16, 16, (2, 2, 128)), (1, 8, 8, (1, 4, 129))])
 def test_winograd_conv3d_vs_torch_and_direct(ecm, B, Ci, Co, dims):
     """nn.Conv3d(k 3, stride 1, pad 1, bias=False) (convbn_3d, cmfsm.py:49-58) on the Winograd kernel: forward and data
     gradient vs CPU F.conv3d autograd, and vs the direct implicit-GEMM kernel (same fp32 class; rounding differs)."""
@@ -711,7 +714,7 @@ def test_winograd_conv3d_vs_torch_and_direct(ecm, B, Ci, Co, dims):
 
 
 @pytest.mark.parametrize("B,Ci,Co,H,W", [(2, 32, 32, 20, 64), (1, 64, 64, 33, 50), (1, 3, 32, 17, 37), (1, 128, 128, 9, 70), (1, 320, 128, 6, 34),
-                                         (2, 32, 480, 12, 40)])
+                                         (2, 32, 480, 12, 40), (1, 8, 8, 5, 2), (1, 8, 8, 4, 3), (1, 64, 64, 7, 65), (1, 16, 16, 6, 128)])
 def test_winograd_conv2d_vs_torch(ecm, B, Ci, Co, H, W):
     """The encoder's 3x3 / stride 1 / pad 1 Conv2d layers (cmfsm.py:36-46) and the P class convolution on the 2-D
     instantiation of the Winograd kernel: forward + data gradient vs CPU F.conv2d autograd."""

@@ -193,53 +193,62 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
 #ifdef WINO_PROFILE
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = clock64();
 #endif
-    // ---- prologue: chunk 0 into buffer 0, chunk 1's patch into registers -------------------------------------------------
-    // chunk c's patch lives in rawA for even c, rawB for odd c
-    // Patch loads are issued for every chunk index up to nchunks + 2 -- beyond the last chunk through an empty descriptor,
-    // which costs no memory access -- so that every wait below is a constant count.
+    // ---- prologue: chunk 0 staged, its first two frequencies' operands in registers, chunks 1 / 2 in flight -------------
+    // chunk c's patch lives in rawA for even c, rawB for odd c.
+    // Patch loads and weight DMAs are issued for every chunk index up to nchunks + 2 -- beyond the last chunk through an
+    // empty descriptor / the last chunk's weights again into the buffer nobody reads -- so that every wait below is a
+    // constant count on every path.
+    float av[4][CIC / 2][KD], bw[4][CIC / 2][NP][TR];
+    // MFMA operands of frequency 4*wave + f of the chunk staged in buffer `buf` -> registers
+    auto read_ops = [&](int buf, int f) {
+        const float* Vc = Vs + buf * VF;
+        const float* Uc = Us + buf * UF;
+        const int xi = wave * 4 + f;
+#pragma unroll
+        for (int kk = 0; kk < CIC / 2; ++kk) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+                    bw[f][kk][p][r] = Vc[(((xi * CIC + kk * 2 + half) * NP + p) * TR + r) * 32 + l31];
+#pragma unroll
+            for (int kd = 0; kd < KD; ++kd) av[f][kk][kd] = Uc[((xi * KD + kd) * CIC + kk * 2 + half) * 32 + l31];
+        }
+    };
+    const int last_chunk = nchunks - 1;
     load_raw(0, rawA);
     dma_u(0, Us);
     load_raw(1, rawB);
     wait_raw(rawA, std::integral_constant<int, NUQ + 8>{});   // younger than chunk 0's patch: its weights, chunk 1's patch
     transform_rows(rawA);
     transform_cols_store(Vs);
+    dma_u(last_chunk < 1 ? last_chunk : 1, Us + UF);
     load_raw(2, rawA);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // chunk 1's patch and the weights of chunk 0 have landed
+    // weights of chunk 0 landed: younger are chunk 1's patch, chunk 1's weights and chunk 2's patch
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 + NUQ) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // raw barrier: see the main loop
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    read_ops(0, 0);
+    read_ops(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
     WN_T(0);
 
-    // One chunk; PAR = c & 1 picks the register buffer that holds chunk c+1's patch (and receives chunk c+3's).
+    // One chunk = four groups of MFMAs (one per frequency of this wave).  Each group carries a slice of the staging work,
+    // small enough to issue in the group's shadow; the operands of a group are read from LDS TWO groups ahead, so neither
+    // their latency nor the rendezvous below is on the critical path of the matrix pipe -- a wave keeps its pipe fed even
+    // while the other workgroup of the CU is in its prologue / epilogue:
+    //   group 0: operands of group 2; transform chunk c+1's patch (loaded two chunks ago) into the other V buffer
+    //   group 1: operands of group 3; wait for chunk c+1's weights (DMA issued a chunk ago) and meet the other waves -- the
+    //            ONLY rendezvous per chunk, taken while every wave still has half a chunk of MFMAs to issue
+    //   group 2: operands of group 0 of chunk c+1; weight DMA of chunk c+2 into the U buffer just vacated
+    //   group 3: operands of group 1 of chunk c+1; patch loads of chunk c+3 into the registers just transformed
+    // No wave overwrites what another may still read: every read of V/U[c] is issued before the rendezvous of chunk c (and
+    // complete at it: lgkmcnt(0)); V[c+2] and U[c+2] are written after it.
     auto chunk_body = [&](int c, f32x2 (&raw_next)[8], auto last) {
         constexpr bool LAST = decltype(last)::value;         // the odd chunk out at the end: nothing left to stage
         const int buf = c & 1;
-        const float* Vc = Vs + buf * VF;
-        const float* Uc = Us + buf * UF;
-        float* Vn = Vs + (buf ^ 1) * VF;
         const bool more = !LAST && c + 1 < nchunks;
-        // (1) MFMA operands of this chunk into registers: frequency 0 first, so that its MFMAs can start as soon as ITS reads
-        //     are back while the other three groups' reads are still in flight
-        float av[4][CIC / 2][KD], bw[4][CIC / 2][NP][TR];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-#pragma unroll
-            for (int kk = 0; kk < CIC / 2; ++kk) {
-                const int xi = wave * 4 + f;
-#pragma unroll
-                for (int p = 0; p < NP; ++p)
-#pragma unroll
-                    for (int r = 0; r < TR; ++r)
-                        bw[f][kk][p][r] = Vc[(((xi * CIC + kk * 2 + half) * NP + p) * TR + r) * 32 + l31];
-#pragma unroll
-                for (int kd = 0; kd < KD; ++kd) av[f][kk][kd] = Uc[((xi * KD + kd) * CIC + kk * 2 + half) * 32 + l31];
-            }
-            if (f == 0) __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        WN_T(1);
-        // (2) the MFMAs, one frequency (KD*CIC/2*NPR of them) at a time, each group followed by a slice of the staging work
-        //     for the chunks ahead, small enough to issue in the shadow of the group's last MFMA.  sched_barriers pin it.
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
 #pragma unroll
@@ -252,28 +261,38 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
                         for (int r = 0; r < TR; ++r)
                             acc[f][p * TR + r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f][kk][kd], bw[f][kk][p + kd][r],
                                                                                       acc[f][p * TR + r], 0, 0, 0);
-            if (f == 0 && more) {                                          // chunk c+1's patch: loaded two chunks ago;
-                wait_raw(raw_next, std::integral_constant<int, NUQ + 8>{});   // younger: weights of chunk c, patch of c+2
-                transform_rows(raw_next);
+            if (f == 0) {
+                read_ops(buf, 2);
+                // chunk c+1's patch, loaded two chunks ago; younger: weights of c+1, patch of c+2.  Waited for even when it
+                // is past the end and unused: until then its registers must not be handed to anything else.
+                wait_raw(raw_next, std::integral_constant<int, NUQ + 8>{});
+                if (more) {
+                    transform_rows(raw_next);
+                    transform_cols_store(Vs + (buf ^ 1) * VF);
+                }
             }
-            if (f == 1 && more) transform_cols_store(Vn);
-            // DMA and patch loads are unconditional (past the end: the last chunk's weights again into the buffer nobody
-            // reads, patches through an empty descriptor), so that every wait is a constant count on every path
-            if (f == 2 && !LAST) dma_u(more ? c + 1 : c, Us + (buf ^ 1) * UF);
-            if (f == 3 && !LAST) load_raw(c + 3, raw_next);               // the buffer just consumed gets chunk c+3's patch
+            if (f == 1) {
+                read_ops(buf, 3);
+                if (!LAST) {
+                    // chunk c+1's weights landed: the only VMEM operations younger than their DMA are chunk c+2's 8 patch loads.
+                    // NOT __syncthreads(): its fence waits vmcnt(0), i.e. for those loads too -- a memory round trip per chunk
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
+            if (f == 2 && !LAST) {
+                if (more) read_ops(buf ^ 1, 0);
+                dma_u(c + 2 < nchunks ? c + 2 : last_chunk, Us + buf * UF);
+            }
+            if (f == 3 && !LAST) {
+                if (more) read_ops(buf ^ 1, 1);
+                load_raw(c + 3, raw_next);                                 // the registers just transformed get chunk c+3's patch
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         WN_T(2);
-        // weight DMA of chunk c+1 landed: the only VMEM operations younger than it are the 8 patch loads of chunk c+3
-        // (chunk c+2's, issued one chunk earlier, are older and are waited for with it -- they have had a full chunk)
-        if (!LAST) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        WN_T(3);
-        // NOT __syncthreads(): its workgroup fence waits vmcnt(0), i.e. for the 8 patch loads issued a moment ago -- a full
-        // memory round trip per chunk.  Own LDS writes done + raw barrier is all the hand-off of V / U needs.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        WN_T(4);
     };
     {
         int c = 0;
@@ -283,6 +302,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
         }
         if (c < nchunks) chunk_body(c, rawB, std::true_type{});
     }
+    // all operand reads done before the epilogue reuses the staging buffers
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
     // The patch loads issued past the last chunk (empty descriptor) still write their registers when they return: keep both
     // buffers allocated until the queue has drained, or the register allocator hands them to the epilogue early.

@@ -10,7 +10,7 @@
 // GEMM per frequency xi in [0,16):  M_xi[co][p][r][t] += sum_{kd,ci} U_xi[kd][ci][co] * V_xi[ci][p+kd][r][t]
 //   A = U_xi : lane l holds U[k = l>>5][co = l&31]            (LDS image [xi][kd][ci][co], global->LDS DMA, double buffered)
 //   B = V_xi : lane l holds V[k = l>>5][tile column t = l&31] (LDS image [xi][ci][plane][tile row][32], double buffered)
-// One workgroup (4 waves) owns TD planes x TR tile rows x 32 tile columns of 2x2 tiles (TD x 2TR x 64 outputs) for 32
+// One workgroup (4 waves) owns TD planes x 32*TR consecutive 2x2 tiles (numbered row-major over the plane) for 32
 // output channels; wave w owns the frequencies 4w..4w+3 (4 x TD*TR accumulators of 16 registers).  Per chunk of CIC input
 // channels every thread transforms ONE 4x4 input patch (8 eight-byte buffer loads, contiguous across the lanes, with hardware
 // zero padding -> 32 adds -> 16 LDS stores), prefetched TWO chunks ahead through registers while the previous chunks' MFMAs
@@ -50,21 +50,22 @@ struct WinoCfg {
 template <int KD, int TD, int TR, int CIC>
 __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict__ x, const float* __restrict__ up,
                                                       float* __restrict__ y, int Ci, int nchunks, int Co, int D, int H,
-                                                      int W, int tiles_d, int tiles_h, int tiles_w) {
+                                                      int W, int tiles_d, int tiles_wt, int ntile, int tblocks) {
     using Cfg = WinoCfg<KD, TD, TR, CIC>;
     constexpr int NP = Cfg::NP, NPR = Cfg::NPR, VF = Cfg::V_FLOATS, UF = Cfg::U_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Vs = smem;                       // 2 x [16][CIC][NP][TR][32]
     float* Us = smem + 2 * VF;              // 2 x [16][KD][CIC][32]
 
+    // The 2x2 output tiles of a plane are numbered row-major (tiles_wt per row, ntile in all) and a workgroup takes 32*TR
+    // CONSECUTIVE ones, wrapping over the row ends: no column padding whatever the image width (240 columns = 120 tiles per
+    // row: 3.75 blocks of 32 when cut per row, 270 exact blocks when flattened).
     int bid = ecm_xcd_tile(blockIdx.x, gridDim.x);
     const int td = bid % tiles_d; bid /= tiles_d;
-    const int tw = bid % tiles_w; bid /= tiles_w;
-    const int th = bid % tiles_h;
-    const int b = bid / tiles_h;
+    const int tb = bid % tblocks;
+    const int b = bid / tblocks;
     const int grp = blockIdx.y;
-    const int od0 = td * TD, oh0 = th * (2 * TR), ow0 = tw * 64;
-
+    const int od0 = td * TD, n0 = tb * (32 * TR);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
 
@@ -78,11 +79,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     // offset (hardware zero fill).  A pair never straddles the end of a row: at the left border pair A is read one column to
     // the right, at the right border pair B one column to the left, and `fix_edges` moves the values into place.
     unsigned poff[8];
-    const int ow_t = ow0 + 2 * l31;                          // first output column of this thread's tile
+    const int n_t = n0 + pr * 32 + l31;                      // this thread's tile; past the last one: everything out of range
+    const int trow_t = n_t / tiles_wt;
+    const int oh_t = 2 * trow_t, ow_t = n_t < ntile ? 2 * (n_t - trow_t * tiles_wt) : W;   // first output row / column
     const bool edge_l = ow_t == 0, edge_r = ow_t + 2 >= W && ow_t + 1 < W;
     {
         const int gz = od0 - KD / 2 + pz;
-        const int gy0 = oh0 - 1 + 2 * pr;
+        const int gy0 = oh_t - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gy = gy0 + i;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
             poff[i * 2 + 1] = ok && ow_t + 1 < W ? (unsigned)(row + ow_t + 1 - (edge_r ? 1 : 0)) * 4u : 0x80000000u;
         }
     }
-    const bool wg_edge = ow0 == 0 || ow0 + 66 > W;          // some tile of this workgroup touches a row end (uniform)
+    const bool wg_edge = __builtin_amdgcn_ballot_w64(edge_l || edge_r) != 0;   // some tile of this wave touches a row end
     const float* xb = x + (size_t)b * Ci * DHWi;
     const unsigned plane_bytes = (unsigned)DHWi * 4u;
     const int pc_u = __builtin_amdgcn_readfirstlane(pc);
@@ -245,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     //   group 3: operands of group 1 of chunk c+1; patch loads of chunk c+3 into the registers just transformed
     // No wave overwrites what another may still read: every read of V/U[c] is issued before the rendezvous of chunk c (and
     // complete at it: lgkmcnt(0)); V[c+2] and U[c+2] are written after it.
-    auto chunk_body = [&](int c, f32x2 (&raw_next)[8], auto last) {
-        constexpr bool LAST = decltype(last)::value;         // the odd chunk out at the end: nothing left to stage
+    auto chunk_body = [&](int c, f32x2 (&raw_next)[8], auto is_last) {
+        constexpr bool LAST = decltype(is_last)::value;         // the odd chunk out at the end: nothing left to stage
         const int buf = c & 1;
         const bool more = !LAST && c + 1 < nchunks;
 #pragma unroll
@@ -320,6 +323,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     const size_t HWo = HWi, DHWo = DHWi;                     // stride 1, pad 1: output volume == input volume
     float* yb = y + (size_t)b * Co * DHWo;
     const bool w_even = (W & 1) == 0;
+    int oh_e[TR], ow_e[TR];                                  // output tile of this thread's column t = l31, per tile-row slot
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        const int n = n0 + r * 32 + l31, trow = n / tiles_wt;
+        oh_e[r] = 2 * trow;
+        ow_e[r] = n < ntile ? 2 * (n - trow * tiles_wt) : W;
+    }
 #pragma unroll
     for (int q = 0; q < NPR; ++q) {
 #pragma unroll
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
             const float y00 = tv[0][0] + tv[1][0] + tv[2][0], y01 = tv[0][1] + tv[1][1] + tv[2][1];
             const float y10 = tv[1][0] - tv[2][0] - tv[3][0], y11 = tv[1][1] - tv[2][1] - tv[3][1];
             const int co = grp * 32 + col;
-            const int od = od0 + q / TR, oh = oh0 + 2 * (q % TR), ow = ow0 + 2 * t;
+            const int od = od0 + q / TR, oh = oh_e[q % TR], ow = ow_e[q % TR];   // t == l31 for every e4
             if (co < Co && od < D && ow < W) {
                 float* yp = yb + (size_t)co * DHWo + (size_t)od * HWo + (size_t)oh * W + ow;
                 const bool two = ow + 1 < W;
@@ -405,15 +415,16 @@ __global__ void pack_wino_weight(const float* __restrict__ w, float* __restrict_
 template <int KD, int TD, int TR, int CIC>
 int launch_wino(const float* x, const float* up, float* y, int B, int Ci, int Co, int D, int H, int W, hipStream_t st) {
     using Cfg = WinoCfg<KD, TD, TR, CIC>;
-    const int tiles_d = (D + TD - 1) / TD, tiles_h = (H + 2 * TR - 1) / (2 * TR), tiles_w = (W + 63) / 64;
-    const long long nblk = (long long)B * tiles_d * tiles_h * tiles_w;
+    const int tiles_d = (D + TD - 1) / TD, tiles_wt = (W + 1) / 2, ntile = ((H + 1) / 2) * tiles_wt;
+    const int tblocks = (ntile + 32 * TR - 1) / (32 * TR);
+    const long long nblk = (long long)B * tiles_d * tblocks;
     const int groups = (Co + 31) / 32, nchunks = (Ci + CIC - 1) / CIC;
     if (nblk > 0x7fffffffLL || groups > 65535 || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
     auto kern = conv_wino_mfma<KD, TD, TR, CIC>;
     const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(256), Cfg::LDS_BYTES, st, x, up, y, Ci, nchunks, Co, D,
-                       H, W, tiles_d, tiles_h, tiles_w);
+                       H, W, tiles_d, tiles_wt, ntile, tblocks);
     return ECM_LAUNCH_RESULT();
 }
 

@@ -407,7 +407,7 @@ def _pack_deconv(w):
 # implicit-GEMM kernels for everything; both are parity-tested.
 import os as _os
 WINOGRAD = _os.environ.get("ECM_WINOGRAD", "1") != "0"
-WINO2D_MIN_CI = 64
+WINO2D_MIN_CI = int(_os.environ.get("ECM_WINO2D_MIN_CI", "32"))
 
 
 def _wino_ok(x):
@@ -610,8 +610,8 @@ class Conv2dG(torch.autograd.Function):
         x = _c(x)
         Co, Ci, kh, kw = w.shape
         same = (kh, kw, stride, dil, pad_top, pad_left) == (3, 3, 1, 1, 1, 1) and (Ho, Wo) == tuple(x.shape[-2:])
-        # Winograd where it is ahead of the direct kernel (tools/wino_time.py): from 64 input channels up -- with 32 the
-        # per-tile transform + exchange costs as much as the multiplies it saves
+        # Winograd where it is ahead of the direct kernel (tools/wino_time.py): from 32 channels up (32->32 at 576x960:
+        # 0.56 vs 0.73 ms); below that (the 3-channel stem) the 16 frequency planes are mostly padding
         ctx.wino_f, ctx.wino_b = _wino_ok(x) and same and Ci >= WINO2D_MIN_CI, _wino_ok(x) and same and Co >= WINO2D_MIN_CI
         ctx.wino_same = same
         if ctx.wino_f:

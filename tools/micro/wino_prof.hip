@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     }
     unsigned long long prof[32];
     (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(wino_prof), sizeof(prof));
-    const char* names[6] = {"setup + prologue", "operand LDS reads", "MFMA groups + staging slices", "vmcnt wait", "barrier", "epilogue"};
+    const char* names[6] = {"setup + prologue", "-", "main loop (MFMA groups with staging slices, rendezvous)", "-", "-", "epilogue"};
     for (int w = 0; w < 4; w += 3) {
         unsigned long long tot = 0; for (int i = 0; i < 6; ++i) tot += prof[w * 8 + i];
         printf("wave %d total %llu cycles\n", w, tot);

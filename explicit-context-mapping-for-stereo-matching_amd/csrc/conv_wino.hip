@@ -39,11 +39,13 @@ struct WinoCfg {
     static constexpr int NPR = TD * TR;                    // (plane, tile row) pairs = accumulators per frequency
     static constexpr int V_FLOATS = 16 * CIC * NP * TR * 32;
     static constexpr int U_FLOATS = 16 * KD * CIC * 32;
-    static constexpr int LDS_FLOATS = 2 * (V_FLOATS + U_FLOATS);
+    static constexpr int STAGE_FLOATS = 2 * (V_FLOATS + U_FLOATS);
+    static constexpr int EPI_FLOATS = NPR * 4 * 2 * 32 * 32;         // epilogue exchange: T[q][4 i][2 b][32 co][32 t]
+    static constexpr int LDS_FLOATS = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static_assert(CIC * NP * TR * 32 == 256, "one input patch per thread per chunk");
     static_assert(CIC % 2 == 0 && (256 / (NP * TR * 32)) == CIC, "channel of a patch must be wave-uniform");
-    static_assert(4 * 2 * 32 * 32 <= LDS_FLOATS, "epilogue exchange buffer must fit");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
 
 // packed weights: [co group][chunk][xi][kd][cc][32 co]  (chunk = CIC input channels; zero rows / columns beyond Ci / Co)
@@ -305,69 +307,80 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
         }
         if (c < nchunks) chunk_body(c, rawB, std::true_type{});
     }
-    // all operand reads done before the epilogue reuses the staging buffers
+    // Before the epilogue reuses the staging buffers: (1) this wave's VMEM queue drained -- the weight DMA issued past the
+    // last chunk still WRITES LDS when it lands, and the patch loads issued past the last chunk (empty descriptor) still
+    // write their registers, which must stay allocated until then; (2) all operand reads done; (3) every wave has got
+    // that far (a DMA of wave B landing after wave A's first exchange write would corrupt it).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(rawA[k]), "v"(rawB[k]));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // The patch loads issued past the last chunk (empty descriptor) still write their registers when they return: keep both
-    // buffers allocated until the queue has drained, or the register allocator hands them to the epilogue early.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(rawA[k]), "v"(rawB[k]));
-
     // ---- epilogue: Y = A^T M A.  Wave w owns frequency ROW i = w (xi = 4w + j), so the column half of the transform,
     // T[i][b] = sum_j M[i][j] A[j][b], is done in registers; only T (2 of 4 values) crosses the waves through LDS:
-    // Ts[4 i][2 b][32 co][32 t] = 32 KB per (plane, tile row) pair q, then Y[a][b] = sum_i A^T[a][i] T[i][b].
+    // Ts[q][4 i][2 b][32 co][32 t] for all (plane, tile row) pairs q at once -- ONE rendezvous -- then
+    // Y[a][b] = sum_i A^T[a][i] T[i][b].  The stores go through a buffer descriptor over this workgroup's 32 output channels:
+    // positions outside the volume (and channels beyond Co) carry the out-of-range offset and are dropped by the hardware,
+    // so the store loop has no branches.
     float* Ts = smem;
-    const size_t HWo = HWi, DHWo = DHWi;                     // stride 1, pad 1: output volume == input volume
-    float* yb = y + (size_t)b * Co * DHWo;
+    const size_t DHWo = DHWi;                                // stride 1, pad 1: output volume == input volume
     const bool w_even = (W & 1) == 0;
-    int oh_e[TR], ow_e[TR];                                  // output tile of this thread's column t = l31, per tile-row slot
 #pragma unroll
-    for (int r = 0; r < TR; ++r) {
-        const int n = n0 + r * 32 + l31, trow = n / tiles_wt;
-        oh_e[r] = 2 * trow;
-        ow_e[r] = n < ntile ? 2 * (n - trow * tiles_wt) : W;
-    }
-#pragma unroll
-    for (int q = 0; q < NPR; ++q) {
+    for (int q = 0; q < NPR; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = (i & 3) + 8 * (i >> 2) + 4 * half;
             const float m0 = acc[0][q][i], m1 = acc[1][q][i], m2 = acc[2][q][i], m3 = acc[3][q][i];
-            Ts[((wave * 2 + 0) * 32 + co) * 32 + l31] = m0 + m1 + m2;
-            Ts[((wave * 2 + 1) * 32 + co) * 32 + l31] = m1 - m2 - m3;
+            Ts[(((q * 4 + wave) * 2 + 0) * 32 + co) * 32 + l31] = m0 + m1 + m2;
+            Ts[(((q * 4 + wave) * 2 + 1) * 32 + co) * 32 + l31] = m1 - m2 - m3;
         }
-        __syncthreads();
+    const int nco = Co - grp * 32 < 32 ? Co - grp * 32 : 32;
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y + ((size_t)b * Co + (size_t)grp * 32) * DHWo, 0,
+                                                       (unsigned)nco * plane_bytes, 0x00020000);
+    unsigned yoff[NPR][2];                                   // this thread's tile column t = l31: byte offset of its two rows
 #pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {                     // 1024 (co, t) pairs per q: 4 per thread
-            const int e = tid + e4 * 256;
-            const int t = e & 31, col = e >> 5;
+    for (int q = 0; q < NPR; ++q) {
+        const int n = n0 + (q % TR) * 32 + l31, trow = n / tiles_wt;
+        const int od = od0 + q / TR, oh = 2 * trow, ow = 2 * (n - trow * tiles_wt);
+        const bool ok = n < ntile && od < D;
+        const unsigned base = (unsigned)((od * H + oh) * W + ow) * 4u;
+        yoff[q][0] = ok ? base : 0x80000000u;
+        yoff[q][1] = ok && oh + 1 < H ? base + (unsigned)W * 4u : 0x80000000u;
+    }
+    const bool has_col1 = w_even;                            // W odd: the second column of the last tile of a row is outside
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes done + raw barrier (no need to drain VMEM)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < NPR; ++q)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {                     // 1024 (co, t) pairs per q: 4 per thread, t == l31 for all of them
+            const int col = (tid >> 5) + 8 * e4;
             float tv[4][2];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int bq = 0; bq < 2; ++bq) tv[i][bq] = Ts[((i * 2 + bq) * 32 + col) * 32 + t];
+                for (int bq = 0; bq < 2; ++bq) tv[i][bq] = Ts[(((q * 4 + i) * 2 + bq) * 32 + col) * 32 + l31];
             const float y00 = tv[0][0] + tv[1][0] + tv[2][0], y01 = tv[0][1] + tv[1][1] + tv[2][1];
             const float y10 = tv[1][0] - tv[2][0] - tv[3][0], y11 = tv[1][1] - tv[2][1] - tv[3][1];
-            const int co = grp * 32 + col;
-            const int od = od0 + q / TR, oh = oh_e[q % TR], ow = ow_e[q % TR];   // t == l31 for every e4
-            if (co < Co && od < D && ow < W) {
-                float* yp = yb + (size_t)co * DHWo + (size_t)od * HWo + (size_t)oh * W + ow;
-                const bool two = ow + 1 < W;
-                if (oh < H) {
-                    if (two && w_even) *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
-                    else { yp[0] = y00; if (two) yp[1] = y01; }
-                }
-                if (oh + 1 < H) {
-                    if (two && w_even) *reinterpret_cast<float2*>(yp + W) = make_float2(y10, y11);
-                    else { yp[W] = y10; if (two) yp[W + 1] = y11; }
-                }
+            const unsigned choff = (unsigned)col * plane_bytes;          // channel beyond Co: >= num_records, dropped
+            if (has_col1) {
+                u32x2 r0 = {__builtin_bit_cast(unsigned, y00), __builtin_bit_cast(unsigned, y01)};
+                u32x2 r1 = {__builtin_bit_cast(unsigned, y10), __builtin_bit_cast(unsigned, y11)};
+                __builtin_amdgcn_raw_buffer_store_b64(r0, yrs, yoff[q][0] + choff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(r1, yrs, yoff[q][1] + choff, 0, 0);
+            } else {
+                const int n = n0 + (q % TR) * 32 + l31;
+                const bool two = 2 * (n % tiles_wt) + 1 < W;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), yrs, yoff[q][0] + choff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), yrs, yoff[q][1] + choff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), yrs, two ? yoff[q][0] + choff + 4u : 0x80000000u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), yrs, two ? yoff[q][1] + choff + 4u : 0x80000000u, 0, 0);
             }
         }
-        if (q + 1 < NPR) __syncthreads();
-    }
 #ifdef WINO_PROFILE
     WN_T(5);
     if (blockIdx.x == 2000 && blockIdx.y == 0 && lane == 0)

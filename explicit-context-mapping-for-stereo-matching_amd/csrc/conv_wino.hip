@@ -51,7 +51,7 @@ struct WinoCfg {
 // packed weights: [co group][chunk][xi][kd][cc][32 co]  (chunk = CIC input channels; zero rows / columns beyond Ci / Co)
 template <int KD, int TD, int TR, int CIC>
 __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict__ x, const float* __restrict__ up,
-                                                      float* __restrict__ y, int Ci, int nchunks, int Co, int D, int H,
+                                                      const float* __restrict__ addend, float* __restrict__ y, int Ci, int nchunks, int Co, int D, int H,
                                                       int W, int tiles_d, int tiles_wt, int ntile, int tblocks) {
     using Cfg = WinoCfg<KD, TD, TR, CIC>;
     constexpr int NP = Cfg::NP, NPR = Cfg::NPR, VF = Cfg::V_FLOATS, UF = Cfg::U_FLOATS;
@@ -350,6 +350,27 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
         yoff[q][1] = ok && oh + 1 < H ? base + (unsigned)W * 4u : 0x80000000u;
     }
     const bool has_col1 = w_even;                            // W odd: the second column of the last tile of a row is outside
+    // y = conv(x) + addend (optional; same shape as y): fetched here, ahead of the rendezvous, through the same offsets --
+    // this is how a data gradient is accumulated onto the gradient arriving over a skip connection without a separate pass
+    float ad[NPR][4][4];
+    if (addend) {
+        const auto ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(addend) + ((size_t)b * Co + (size_t)grp * 32) * DHWo, 0,
+                                                           (unsigned)nco * plane_bytes, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < NPR; ++q)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const unsigned choff = (unsigned)((tid >> 5) + 8 * e4) * plane_bytes;
+                const int n = n0 + (q % TR) * 32 + l31;
+                const bool two = 2 * (n % tiles_wt) + 1 < W;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    ad[q][e4][r * 2 + 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, yoff[q][r] + choff, 0, 0));
+                    ad[q][e4][r * 2 + 1] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(ars, two ? yoff[q][r] + choff + 4u : 0x80000000u, 0, 0));
+                }
+            }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes done + raw barrier (no need to drain VMEM)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -364,8 +385,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int bq = 0; bq < 2; ++bq) tv[i][bq] = Ts[(((q * 4 + i) * 2 + bq) * 32 + col) * 32 + l31];
-            const float y00 = tv[0][0] + tv[1][0] + tv[2][0], y01 = tv[0][1] + tv[1][1] + tv[2][1];
-            const float y10 = tv[1][0] - tv[2][0] - tv[3][0], y11 = tv[1][1] - tv[2][1] - tv[3][1];
+            float y00 = tv[0][0] + tv[1][0] + tv[2][0], y01 = tv[0][1] + tv[1][1] + tv[2][1];
+            float y10 = tv[1][0] - tv[2][0] - tv[3][0], y11 = tv[1][1] - tv[2][1] - tv[3][1];
+            if (addend) { y00 += ad[q][e4][0]; y01 += ad[q][e4][1]; y10 += ad[q][e4][2]; y11 += ad[q][e4][3]; }
             const unsigned choff = (unsigned)col * plane_bytes;          // channel beyond Co: >= num_records, dropped
             if (has_col1) {
                 u32x2 r0 = {__builtin_bit_cast(unsigned, y00), __builtin_bit_cast(unsigned, y01)};
@@ -426,7 +448,7 @@ __global__ void pack_wino_weight(const float* __restrict__ w, float* __restrict_
 }
 
 template <int KD, int TD, int TR, int CIC>
-int launch_wino(const float* x, const float* up, float* y, int B, int Ci, int Co, int D, int H, int W, hipStream_t st) {
+int launch_wino(const float* x, const float* up, const float* addend, float* y, int B, int Ci, int Co, int D, int H, int W, hipStream_t st) {
     using Cfg = WinoCfg<KD, TD, TR, CIC>;
     const int tiles_d = (D + TD - 1) / TD, tiles_wt = (W + 1) / 2, ntile = ((H + 1) / 2) * tiles_wt;
     const int tblocks = (ntile + 32 * TR - 1) / (32 * TR);
@@ -436,7 +458,7 @@ int launch_wino(const float* x, const float* up, float* y, int B, int Ci, int Co
     auto kern = conv_wino_mfma<KD, TD, TR, CIC>;
     const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(256), Cfg::LDS_BYTES, st, x, up, y, Ci, nchunks, Co, D,
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(256), Cfg::LDS_BYTES, st, x, up, addend, y, Ci, nchunks, Co, D,
                        H, W, tiles_d, tiles_wt, ntile, tblocks);
     return ECM_LAUNCH_RESULT();
 }
@@ -462,12 +484,25 @@ extern "C" int ecm_conv_wino_pack_weight(const float* w, float* packed, int Co, 
     return ECM_LAUNCH_RESULT();
 }
 
-extern "C" int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int Ci, int Co, int D, int H, int W,
-                                 int kd, void* stream) {
+namespace {
+int wino_dispatch(const float* x, const float* upacked, const float* addend, float* y, int B, int Ci, int Co, int D, int H, int W,
+                  int kd, void* stream) {
     ECM_CHECK_ARG(x && upacked && y && B > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0);
     if (W < 2) return ECM_EUNSUP;                            // patches are read as pairs of neighbouring columns
     hipStream_t st = ecm_stream(stream);
-    if (kd == 3) return launch_wino<3, 2, 1, WINO_CIC3>(x, upacked, y, B, Ci, Co, D, H, W, st);
-    if (kd == 1) return launch_wino<1, 1, 2, WINO_CIC2>(x, upacked, y, B, Ci, Co, D, H, W, st);   // D independent planes
+    if (kd == 3) return launch_wino<3, 2, 1, WINO_CIC3>(x, upacked, addend, y, B, Ci, Co, D, H, W, st);
+    if (kd == 1) return launch_wino<1, 1, 2, WINO_CIC2>(x, upacked, addend, y, B, Ci, Co, D, H, W, st);   // D independent planes
     return ECM_EUNSUP;
+}
+}  // namespace
+
+extern "C" int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int Ci, int Co, int D, int H, int W,
+                                 int kd, void* stream) {
+    return wino_dispatch(x, upacked, nullptr, y, B, Ci, Co, D, H, W, kd, stream);
+}
+
+extern "C" int ecm_conv_wino_fwd_add(const float* x, const float* upacked, const float* addend, float* y, int B, int Ci, int Co,
+                                     int D, int H, int W, int kd, void* stream) {
+    ECM_CHECK_ARG(addend);
+    return wino_dispatch(x, upacked, addend, y, B, Ci, Co, D, H, W, kd, stream);
 }

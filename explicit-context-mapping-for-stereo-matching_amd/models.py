@@ -37,8 +37,10 @@ EXPLICIT_COST_VOLUME = _os.environ.get("ECM_EXPLICIT_COST_VOLUME", "0") == "1"
 # layouts are exactly the reference's, with forward() on the HIP kernels.
 # ------------------------------------------------------------------------------------------------
 class HipConv3d(nn.Conv3d):
-    def forward(self, x):
-        return ops.conv3d_k3(x, self.weight, self.stride[0])
+    def forward(self, x, fork=False):
+        """fork=True: returns (y, x') -- x' is x for the skip connection, its gradient folded into this layer's data-gradient
+        kernel (ops._fork_out)."""
+        return ops.conv3d_k3(x, self.weight, self.stride[0], fork)
 
 
 class HipConvTranspose3d(nn.ConvTranspose3d):
@@ -73,12 +75,14 @@ class EncConv2d(nn.Conv2d):
                 and self.dilation[0] == self.dilation[1] and self.padding == (d * (kh - 1) // 2, d * (kw - 1) // 2)
                 and self.padding_mode == "zeros" and ops.conv2d_supported(self.in_channels, self.out_channels, kh, kw, s, d))
 
-    def forward(self, x):
+    def forward(self, x, fork=False):
+        """fork=True: returns (y, x') -- x' is x for the skip connection (ops._fork_out)."""
         if x.dim() == 5:       # [B,C,d*d,H/d,W/d]: the phase planes of a dilation-d layer (feature_extraction._run_layer)
-            return ops.conv2d_planes(x, self.weight)
-        if self._native():
-            return ops.conv2d(x, self.weight, self.stride[0], self.dilation[0])      # raises on CPU tensors, like every op
-        return super().forward(x)
+            return ops.conv2d_planes(x, self.weight, fork)
+        if self._native():     # raises on CPU tensors, like every op
+            return ops.conv2d(x, self.weight, self.stride[0], self.dilation[0], fork=fork)
+        y = super().forward(x)
+        return (y, x) if fork else y
 
 
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
@@ -136,8 +140,12 @@ def _costvol_dres0(dres0, lr_l, lr_r, ndisp):
     return gn.fused(ops.costvol_conv3d(lr_l, lr_r, conv.weight, ndisp), None, True)
 
 
-def _cbn(seq, x, skip=None, relu=False):
-    """Run a convbn_3d Sequential with the trailing residual/ReLU fused into the GroupNorm kernel."""
+def _cbn(seq, x, skip=None, relu=False, fork=False):
+    """Run a convbn_3d Sequential with the trailing residual/ReLU fused into the GroupNorm kernel.
+    fork=True: returns (out, x') where x' stands for x in the skip connection that also consumes it."""
+    if fork:
+        y, xs = seq[0](x, fork=True)
+        return seq[1].fused(y, skip, relu), xs
     return seq[1].fused(seq[0](x), skip, relu)
 
 
@@ -155,8 +163,12 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = _seq_fused(self.conv1, x)                                    # conv + GN + ReLU
-        if self.downsample is not None:
+        if self.downsample is None:
+            # x feeds conv1 AND the residual add: conv1 hands x back so that its data gradient absorbs the skip gradient
+            y, x = self.conv1[0][0](x, fork=True)
+            out = self.conv1[0][1].fused(y, None, True)                    # GN + ReLU
+        else:
+            out = _seq_fused(self.conv1, x)                                # conv + GN + ReLU
             x = _seq_fused(self.downsample, x)
         return self.conv2[1].fused(self.conv2[0](out), x, False)            # conv + GN + residual add (cmfsm.py:76-85)
 
@@ -421,14 +433,17 @@ class cmfsm(nn.Module):
         w9 = self.mapping_matrix.weights(lr_l, hr_l)                                   # :664
         cost0 = _costvol_dres0(self.dres0, lr_l, lr_r, self.maxdisp // scale)          # :667-684
         cost0 = _cbn(self.dres0[2], cost0, relu=True)
-        y = _cbn(self.dres1[0], cost0, relu=True)                                      # :685
+        y, cost0 = _cbn(self.dres1[0], cost0, relu=True, fork=True)                    # :685
         cost0 = _cbn(self.dres1[2], y, skip=cost0)
+        # out1 / out2 feed the next hourglass AND their classifier: the classifier's first convolution hands them back
+        # (fork), so that its data gradient absorbs the gradient arriving through the hourglass
         out1, pre1, post1 = self.dres2(cost0, None, None, residual=cost0)              # :686-687
+        h1, out1 = _cbn(self.classif1[0], out1, relu=True, fork=True)                  # :695
         out2, pre2, post2 = self.dres3(out1, pre1, post1, residual=cost0)              # :689-690
+        h2, out2 = _cbn(self.classif2[0], out2, relu=True, fork=True)                  # :724
         out3, pre3, post3 = self.dres4(out2, pre1, post2, residual=cost0)              # :692-693
-        heads = []
-        for clf, out in ((self.classif1, out1), (self.classif2, out2), (self.classif3, out3)):
-            heads.append(clf[2](_cbn(clf[0], out, relu=True)).squeeze(1))               # :695,724,747
+        h3 = _cbn(self.classif3[0], out3, relu=True)                                   # :747
+        heads = [clf[2](h).squeeze(1) for clf, h in ((self.classif1, h1), (self.classif2, h2), (self.classif3, h3))]
         disp = ops.softargmin_heads(torch.stack(heads, 0))                             # :703-706,725-728,748-753
         preds = ops.ecm_aggregate9(disp, w9, scale)                                    # :709-723 (x3)
         return preds[0].unsqueeze(1), preds[1].unsqueeze(1), preds[2].unsqueeze(1)
@@ -516,15 +531,20 @@ class _ECMNet(nn.Module):
             planes = self.mapping_matrix.planes(lr_l, hr_l, lr_r, hr_r)
         cost0 = _costvol_dres0(self.dres0, lr_l, lr_r, self.maxdisp // scale)
         cost0 = _cbn(self.dres0[2], cost0, relu=True)
-        cost0 = _cbn(self.dres1[2], _cbn(self.dres1[0], cost0, relu=True), skip=cost0)
+        y, cost0 = _cbn(self.dres1[0], cost0, relu=True, fork=True)
+        cost0 = _cbn(self.dres1[2], y, skip=cost0)
         heads, x, pre1, post = [], cost0, None, None
         for i in range(self.HOURGLASSES):
             out, pre, post = getattr(self, f"dres{i + 2}")(x, pre1 if i > 0 else None, post, residual=cost0)
             if i == 0:
                 pre1 = pre
-            x = out
             clf = getattr(self, f"classif{i + 1}")
-            heads.append(clf[2](_cbn(clf[0], out, relu=True)).squeeze(1))
+            if i + 1 < self.HOURGLASSES:       # `out` also feeds the next hourglass: the classifier's conv hands it back
+                h, out = _cbn(clf[0], out, relu=True, fork=True)
+            else:
+                h = _cbn(clf[0], out, relu=True)
+            x = out
+            heads.append(clf[2](h).squeeze(1))
         c = torch.stack(heads, 0)                                        # raw classifier outputs [NH,B,Dl,h,w]
         if self.HEAD == "five":                                          # cmfsm_sub_8.py:757-803 (heads NOT accumulated)
             disp = torch.cat([ops.softargmin_heads(c[k:k + 1]) for k in range(c.shape[0])], 0)

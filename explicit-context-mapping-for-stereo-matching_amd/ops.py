@@ -428,13 +428,34 @@ def _wino_pack(w, kd, flip_transpose):
     return _cached_pack(w, ("wT" if flip_transpose else "w") + str(kd), build)
 
 
-def _wino_run(x, packed, Co, kd):
+def _wino_run(x, packed, Co, kd, addend=None):
     """x: [B,Ci,D,H,W] (kd 3; or kd 1 on D independent planes) or [B,Ci,H,W] (kd 1) -> same spatial shape with Co channels."""
     B, Ci = x.shape[:2]
     D, H, W = (x.shape[2:] if x.dim() == 5 else (1,) + tuple(x.shape[2:]))
     y = torch.empty((B, Co) + tuple(x.shape[2:]), device=x.device, dtype=x.dtype)
-    _lib.call("ecm_conv_wino_fwd", _p(x), _p(packed), _p(y), B, Ci, Co, D, H, W, kd, _stream())
+    if addend is None:
+        _lib.call("ecm_conv_wino_fwd", _p(x), _p(packed), _p(y), B, Ci, Co, D, H, W, kd, _stream())
+    else:                                     # y = conv(x) + addend in the kernel's epilogue (see _fork_grad)
+        if addend.shape != y.shape:
+            raise RuntimeError("addend must have the shape of the convolution's output")
+        _lib.call("ecm_conv_wino_fwd_add", _p(x), _p(packed), _p(_c(addend)), _p(y), B, Ci, Co, D, H, W, kd, _stream())
     return y
+
+
+# ---- forks: a tensor consumed by a convolution AND by a skip connection ----------------------------------------------------
+# Autograd sums the two gradients with a separate elementwise pass (3 passes over the tensor).  With `fork=True` a
+# convolution Function also returns its input (as a view), to be used as the skip operand; its backward then receives the
+# skip gradient next to the output gradient and adds it in the epilogue of the data-gradient kernel (Winograd path: one extra
+# read instead of read + read + write; other paths: a plain add, i.e. what autograd would have done).
+def _fork_out(y, x, fork):
+    return (y, x.view_as(x)) if fork else y
+
+
+def _fork_grad(gx, gskip):
+    """data gradient + skip gradient where the kernel could not take the addend"""
+    if gskip is None:
+        return gx
+    return gskip if gx is None else gx + gskip
 
 
 def _conv_fwd(x, packed, Co, stride):
@@ -481,9 +502,10 @@ class Conv3dK3(torch.autograd.Function):
     """nn.Conv3d(k=3, pad=1, stride 1|2, bias=False) (cmfsm.py:52-57)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride):
+    def forward(ctx, x, w, stride, fork=False):
         _chk(x, w)
         x, w = _c(x), _c(w)
+        ctx.set_materialize_grads(False)
         if _is_c1(w, stride):
             B, Ci, D, H, W = x.shape
             y = torch.empty(B, 1, D, H, W, device=x.device, dtype=x.dtype)
@@ -494,25 +516,28 @@ class Conv3dK3(torch.autograd.Function):
             y = _conv_fwd(x, _pack_conv(w), w.shape[0], stride)
         ctx.save_for_backward(x, w)
         ctx.stride = stride
-        return y
+        return _fork_out(y, x, fork)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, w = ctx.saved_tensors
+        if gy is None:                         # only the forked input was used downstream
+            return gskip, None, None, None
         gy = _c(gy)
         Co, Ci = w.shape[0], w.shape[1]
         gx = gw = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.stride == 1 and _wino_ok(x) and not _is_c1(w, ctx.stride):
+            gx = _wino_run(gy, _wino_pack(w, 3, True), Ci, 3, addend=gskip)
+        elif ctx.needs_input_grad[0]:
             if _is_c1(w, ctx.stride):
                 gx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
                 _lib.call("ecm_conv3d_c1_dgrad", _p(gy), _p(w), _p(gx), x.shape[0], Ci, x.shape[2], x.shape[3], x.shape[4],
                           _stream())
-            elif ctx.stride == 1 and _wino_ok(x):
-                gx = _wino_run(gy, _wino_pack(w, 3, True), Ci, 3)
             elif ctx.stride == 1:
                 gx = _conv_fwd(gy, _pack_conv(w, True), Ci, 1)
             else:
                 gx = _deconv_fwd(gy, _pack_deconv(w), Ci, x.shape[2:])
+            gx = _fork_grad(gx, gskip)
         if ctx.needs_input_grad[1]:
             if _is_c1(w, ctx.stride):
                 B, _, D, H, W = x.shape
@@ -523,7 +548,7 @@ class Conv3dK3(torch.autograd.Function):
                           _stream())
             else:
                 gw = _wgrad(x, gy, Co, Ci, ctx.stride)
-        return gx, gw, None
+        return gx, gw, None, None
 
 
 def _is_c1(w, stride):
@@ -605,9 +630,10 @@ class Conv2dG(torch.autograd.Function):
     same kernel on flipped / transposed weights; stride 2: the transposed-conv kernel) and weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, dil, pad_top, pad_left, Ho, Wo):
+    def forward(ctx, x, w, stride, dil, pad_top, pad_left, Ho, Wo, fork=False):
         _chk(x, w)
         x = _c(x)
+        ctx.set_materialize_grads(False)
         Co, Ci, kh, kw = w.shape
         same = (kh, kw, stride, dil, pad_top, pad_left) == (3, 3, 1, 1, 1, 1) and (Ho, Wo) == tuple(x.shape[-2:])
         # Winograd where it is ahead of the direct kernel (tools/wino_time.py): from 32 channels up (32->32 at 576x960:
@@ -620,11 +646,13 @@ class Conv2dG(torch.autograd.Function):
             y = _conv2d_run(x, _pack2d(w, False), Co, kh, kw, stride, dil, pad_top, pad_left, Ho, Wo)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, dil, pad_top, pad_left, Ho, Wo)
-        return y
+        return _fork_out(y, x, fork)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, w = ctx.saved_tensors
+        if gy is None:
+            return (gskip,) + (None,) * 8
         stride, dil, pad_top, pad_left, Ho, Wo = ctx.cfg
         Co, Ci, kh, kw = w.shape
         B, _, H, W = x.shape
@@ -632,7 +660,8 @@ class Conv2dG(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             if ctx.wino_b:
-                gx = _wino_run(gy, _wino_pack(_c(w), 1, True), Ci, 1)
+                gx = _wino_run(gy, _wino_pack(_c(w), 1, True), Ci, 1, addend=gskip)
+                gskip = None
             elif stride == 1:
                 # gx[i] = sum_k w[k] gy[i + pad - k*dil]: the conv of gy with the flipped kernel, padding (K-1)*dil - pad
                 gx = _conv2d_run(gy, _pack2d(w, True), Ci, kh, kw, 1, dil, (kh - 1) * dil - pad_top, (kw - 1) * dil - pad_left,
@@ -654,6 +683,7 @@ class Conv2dG(torch.autograd.Function):
                 small = _conv2d_run(gy, _pack2d(w, True), Ci, 1, 1, 1, 1, 0, 0, Ho, Wo)
                 gx = torch.zeros(B, Ci, H, W, device=x.device, dtype=x.dtype)
                 gx[:, :, ::2, ::2] = small
+            gx = _fork_grad(gx, gskip)
         if ctx.needs_input_grad[1] and ctx.wino_same and WINOGRAD and WINOGRAD_WGRAD:
             gw = _wino_wgrad(x, gy, Co, Ci, 1)
         elif ctx.needs_input_grad[1]:
@@ -662,11 +692,12 @@ class Conv2dG(torch.autograd.Function):
             scratch = _scratch(nb, x.device)
             _lib.call("ecm_conv2d_wgrad_ex", _p(x), _p(gy), _p(gw), _p(scratch), C.c_longlong(nb), B, Ci, Co, H, W, kh, kw,
                       stride, dil, pad_top, pad_left, Ho, Wo, _stream())
-        return gx, gw, None, None, None, None, None, None
+        return gx, gw, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, stride=1, dil=1, pad_top=None, pad_left=None, Ho=None, Wo=None):
-    """General native 2-D convolution; default padding "same-style" dil*(k-1)/2 and the matching output size."""
+def conv2d(x, w, stride=1, dil=1, pad_top=None, pad_left=None, Ho=None, Wo=None, fork=False):
+    """General native 2-D convolution; default padding "same-style" dil*(k-1)/2 and the matching output size.
+    fork=True: returns (y, x') with x' a view of x to be used as the skip operand (see _fork_out)."""
     kh, kw = w.shape[-2:]
     H, W = x.shape[-2:]
     pt = dil * (kh - 1) // 2 if pad_top is None else int(pad_top)
@@ -675,7 +706,7 @@ def conv2d(x, w, stride=1, dil=1, pad_top=None, pad_left=None, Ho=None, Wo=None)
         Ho = (H + 2 * pt - dil * (kh - 1) - 1) // stride + 1
     if Wo is None:
         Wo = (W + 2 * pl - dil * (kw - 1) - 1) // stride + 1
-    return Conv2dG.apply(x, w, int(stride), int(dil), pt, pl, int(Ho), int(Wo))
+    return Conv2dG.apply(x, w, int(stride), int(dil), pt, pl, int(Ho), int(Wo), bool(fork))
 
 
 def conv2d_k3(x, w):
@@ -704,27 +735,31 @@ class Conv2dPlanes(torch.autograd.Function):
     the Winograd kernels: forward, data gradient and weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, fork=False):
         _chk(x, w)
         x, w = _c(x), _c(w)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, w)
-        return _wino_run(x, _wino_pack(w, 1, False), w.shape[0], 1)
+        return _fork_out(_wino_run(x, _wino_pack(w, 1, False), w.shape[0], 1), x, fork)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, w = ctx.saved_tensors
+        if gy is None:
+            return gskip, None, None
         gy = _c(gy)
-        gx = _wino_run(gy, _wino_pack(w, 1, True), w.shape[1], 1) if ctx.needs_input_grad[0] else None
+        gx = _wino_run(gy, _wino_pack(w, 1, True), w.shape[1], 1, addend=gskip) if ctx.needs_input_grad[0] else None
         gw = _wino_wgrad(x, gy, w.shape[0], w.shape[1], 1) if ctx.needs_input_grad[1] else None
-        return gx, gw
+        return gx, gw, None
 
 
-def conv2d_planes(x, w):
-    return Conv2dPlanes.apply(x, w)
+def conv2d_planes(x, w, fork=False):
+    return Conv2dPlanes.apply(x, w, bool(fork))
 
 
-def conv3d_k3(x, w, stride=1):
-    return Conv3dK3.apply(x, w, int(stride))
+def conv3d_k3(x, w, stride=1, fork=False):
+    """fork=True: returns (y, x') with x' a view of x to be used as the skip operand (see _fork_out)."""
+    return Conv3dK3.apply(x, w, int(stride), bool(fork))
 
 
 class Deconv3dK3S2(torch.autograd.Function):

@@ -136,6 +136,11 @@ long long ecm_conv_wino_packed_floats(int Ci, int Co, int kd);
 int ecm_conv_wino_pack_weight(const float* w, float* packed, int Co, int Ci, int kd, int flip_transpose, void* stream);
 int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int Ci, int Co, int D, int H, int W, int kd,
                       void* stream);
+/* y = conv(x) + addend, addend shaped like y and added in the kernel's epilogue: with the data-gradient weights this is
+ * autograd's accumulation at a skip connection (gx = dgrad(gy) + g_skip; BasicBlock cmfsm.py:76-85, dres1 612-613, the
+ * hourglass / classifier inputs 636-660) without the separate elementwise pass.  y may not alias addend. */
+int ecm_conv_wino_fwd_add(const float* x, const float* upacked, const float* addend, float* y, int B, int Ci, int Co, int D,
+                          int H, int W, int kd, void* stream);
 
 /* Weight gradient of the same stride-1 convolutions in Winograd form: gw = G^T [ sum_tiles (A gy A^T) (.) (B^T x B) ] G, the
  * per-lane operand transforms done on the fly from the raw LDS tiles of ecm_conv3d_k3_wgrad's kernel (conv3d_wgrad.hip).

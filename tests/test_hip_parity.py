@@ -762,6 +762,47 @@ def test_winograd_wgrad2d_vs_torch(ecm, B, Ci, Co, H, W):
     close(got, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))
 
 
+@pytest.mark.parametrize("shape,Co", [((2, 32, 5, 7, 70), 32), ((1, 64, 3, 9, 33), 64), ((1, 32, 20, 64), 32), ((2, 64, 33, 50), 64),
+                                      ((1, 128, 4, 12, 20), 128)])
+def test_fork_folds_skip_gradient_into_data_gradient(ecm, shape, Co):
+    """A tensor consumed by a convolution and by a skip connection (BasicBlock cmfsm.py:76-85, dres1 612-613, the hourglass
+    outputs 686-695): with fork=True the convolution returns its input for the skip branch and its backward adds the skip
+    gradient in the epilogue of the Winograd data-gradient kernel (ecm_conv_wino_fwd_add).  Against CPU autograd of the
+    same graph, and against the unforked graph on the device (where autograd does the addition)."""
+    three = len(shape) == 5 and shape[1] != 128
+    planes = len(shape) == 5 and not three                   # [B,C,P,h,w]: phase planes of a dilated layer
+    x = seeded("fk.x", *shape)
+    Ci = shape[1]
+    w = seeded("fk.w", Co, Ci, *((3, 3, 3) if three else (3, 3))) * (2.0 / ((27 if three else 9) * Ci)) ** 0.5
+    G1 = seeded("fk.g1", shape[0], Co, *shape[2:])
+    G2 = seeded("fk.g2", *shape)
+    xs, ws = x.clone().requires_grad_(), w.clone().requires_grad_()
+    if three:
+        ref = F.conv3d(xs, ws, None, 1, 1)
+    elif planes:
+        B, C, P, h, wd = shape
+        ref = F.conv2d(xs.permute(0, 2, 1, 3, 4).reshape(B * P, C, h, wd), ws, None, 1, 1).view(B, P, Co, h, wd).permute(0, 2, 1, 3, 4)
+    else:
+        ref = F.conv2d(xs, ws, None, 1, 1)
+    ((ref * G1).sum() + (xs * xs * G2).sum()).backward()
+    res = []
+    for fork in (True, False):
+        xg, wg = dev(x).requires_grad_(), dev(w).requires_grad_()
+        op = ecm.ops.conv3d_k3 if three else ecm.ops.conv2d_planes if planes else ecm.ops.conv2d
+        args = (xg, wg, 1) if three else (xg, wg) if planes else (xg, wg, 1, 1)
+        if fork:
+            y, xa = op(*args, fork=True)
+            assert xa.data_ptr() == xg.data_ptr()
+        else:
+            y, xa = op(*args), xg
+        ((y * dev(G1)).sum() + (xa * xa * dev(G2)).sum()).backward()
+        close(y, ref, 1e-4, 2e-5)
+        close(xg.grad, xs.grad, 1e-4, 5e-5)
+        close(wg.grad, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))
+        res.append(xg.grad.cpu())
+    close(res[0], res[1], 1e-5, 1e-5)
+
+
 @pytest.mark.parametrize("B,C,H,W,d", [(2, 128, 24, 40, 2), (1, 64, 16, 36, 2), (1, 128, 16, 32, 4)])
 def test_dilated_layer_as_phase_planes(ecm, B, C, H, W, d):
     """A dilation-d 3x3 convolution (feature_extraction layer4, cmfsm.py:150) run as d*d phase planes on the Winograd

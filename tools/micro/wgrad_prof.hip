@@ -4,8 +4,11 @@
 #include <cstdio>
 #include <vector>
 int main(int argc, char** argv) {
-    const int stride = argc > 1 ? atoi(argv[1]) : 1;        // 0: the 2-D (encoder) variant on 8 x 32 x 576 x 960
-    const bool two_d = stride == 0;
+    // 1 | 2: direct 3-D weight gradient with that stride;  3: Winograd form of the stride-1 3-D layer;
+    // 0: Winograd 2-D (encoder) variant on 8 x 32 x 576 x 960
+    const int mode = argc > 1 ? atoi(argv[1]) : 3;
+    const int stride = mode == 2 ? 2 : 1;
+    const bool two_d = mode == 0, wino = mode == 0 || mode == 3;
     const int B = two_d ? 8 : 1, Ci = 32, Co = 32, D = two_d ? 1 : 48, H = two_d ? 576 : 144, W = two_d ? 960 : 240;
     const int st_ = two_d ? 1 : stride;
     const int Do = (D - 1) / st_ + 1, Ho = (H - 1) / st_ + 1, Wo = (W - 1) / st_ + 1;
@@ -13,14 +16,14 @@ int main(int argc, char** argv) {
     float *x, *g, *gw; void* scratch;
     hipMalloc(&x, nx * 4); hipMalloc(&g, ng * 4); hipMalloc(&gw, (size_t)Co * Ci * 27 * 4);
     hipMemset(x, 0, nx * 4); hipMemset(g, 0, ng * 4);
-    const long long sb = two_d ? ecm_conv2d_k3_wgrad_scratch_bytes(B, Ci, Co, H, W)
-                               : ecm_conv3d_wgrad_scratch_bytes(B, Ci, Co, D, H, W, stride);
+    const long long sb = wino ? ecm_conv_wino_wgrad_scratch_bytes(B, Ci, Co, D, H, W, two_d ? 1 : 3)
+                              : ecm_conv3d_wgrad_scratch_bytes(B, Ci, Co, D, H, W, stride);
     hipMalloc(&scratch, sb);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int r = 0; r < 3; ++r) {
         hipEventRecord(e0);
-        int rc = two_d ? ecm_conv2d_k3_wgrad(x, g, gw, scratch, sb, B, Ci, Co, H, W, nullptr)
-                       : ecm_conv3d_k3_wgrad(x, g, gw, scratch, sb, B, Ci, Co, D, H, W, stride, nullptr);
+        int rc = wino ? ecm_conv_wino_wgrad(x, g, gw, scratch, sb, B, Ci, Co, D, H, W, two_d ? 1 : 3, nullptr)
+                      : ecm_conv3d_k3_wgrad(x, g, gw, scratch, sb, B, Ci, Co, D, H, W, stride, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("rc=%d  %.3f ms\n", rc, ms);

@@ -1,0 +1,46 @@
+// n-ary elementwise sum: out = ((a + b) + c) + d in that fixed order (c, d optional).  This is the gradient accumulation of a
+// tensor with several consumers (cost0 feeds the first hourglass and the residual adds of all three, cmfsm.py:686-693) done
+// in ONE pass -- n reads + 1 write -- instead of autograd's n-1 binary adds (3 passes each).  HBM-bound: 16-byte lanes.
+#include "common.h"
+
+namespace {
+
+template <int N>
+__global__ __launch_bounds__(256) void sum_n_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    const float* __restrict__ c, const float* __restrict__ d,
+                                                    float* __restrict__ out, long long n4, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(a)[i];
+        const float4 w = reinterpret_cast<const float4*>(b)[i];
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        if (N >= 3) { const float4 u = reinterpret_cast<const float4*>(c)[i]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        if (N >= 4) { const float4 u = reinterpret_cast<const float4*>(d)[i]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+    // tail (n % 4 elements) by the first threads of the grid
+    const long long t = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        float v = a[t] + b[t];
+        if (N >= 3) v += c[t];
+        if (N >= 4) v += d[t];
+        out[t] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int ecm_sum_n(const float* a, const float* b, const float* c, const float* d, float* out, long long n, void* stream) {
+    ECM_CHECK_ARG(a && b && out && n > 0 && (c || !d));
+    if ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(c) | reinterpret_cast<size_t>(d) |
+         reinterpret_cast<size_t>(out)) & 15)
+        return ECM_EUNSUP;                                   // 16-byte aligned operands (torch allocations are)
+    hipStream_t st = ecm_stream(stream);
+    const long long n4 = n / 4;
+    const long long want = (n4 + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : want > 256 * 16 ? 256 * 16 : want);
+    if (d) hipLaunchKernelGGL(sum_n_kernel<4>, dim3(blocks), dim3(256), 0, st, a, b, c, d, out, n4, n);
+    else if (c) hipLaunchKernelGGL(sum_n_kernel<3>, dim3(blocks), dim3(256), 0, st, a, b, c, d, out, n4, n);
+    else hipLaunchKernelGGL(sum_n_kernel<2>, dim3(blocks), dim3(256), 0, st, a, b, c, d, out, n4, n);
+    return ECM_LAUNCH_RESULT();
+}

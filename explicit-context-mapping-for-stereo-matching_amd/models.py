@@ -437,11 +437,13 @@ class cmfsm(nn.Module):
         cost0 = _cbn(self.dres1[2], y, skip=cost0)
         # out1 / out2 feed the next hourglass AND their classifier: the classifier's first convolution hands them back
         # (fork), so that its data gradient absorbs the gradient arriving through the hourglass
-        out1, pre1, post1 = self.dres2(cost0, None, None, residual=cost0)              # :686-687
+        # cost0 has four consumers (first hourglass + three residual adds): one 4-ary gradient sum instead of three adds
+        c_in, c_r1, c_r2, c_r3 = ops.fork(cost0, 4)
+        out1, pre1, post1 = self.dres2(c_in, None, None, residual=c_r1)                # :686-687
         h1, out1 = _cbn(self.classif1[0], out1, relu=True, fork=True)                  # :695
-        out2, pre2, post2 = self.dres3(out1, pre1, post1, residual=cost0)              # :689-690
+        out2, pre2, post2 = self.dres3(out1, pre1, post1, residual=c_r2)               # :689-690
         h2, out2 = _cbn(self.classif2[0], out2, relu=True, fork=True)                  # :724
-        out3, pre3, post3 = self.dres4(out2, pre1, post2, residual=cost0)              # :692-693
+        out3, pre3, post3 = self.dres4(out2, pre1, post2, residual=c_r3)               # :692-693
         h3 = _cbn(self.classif3[0], out3, relu=True)                                   # :747
         heads = [clf[2](h).squeeze(1) for clf, h in ((self.classif1, h1), (self.classif2, h2), (self.classif3, h3))]
         disp = ops.softargmin_heads(torch.stack(heads, 0))                             # :703-706,725-728,748-753
@@ -533,9 +535,10 @@ class _ECMNet(nn.Module):
         cost0 = _cbn(self.dres0[2], cost0, relu=True)
         y, cost0 = _cbn(self.dres1[0], cost0, relu=True, fork=True)
         cost0 = _cbn(self.dres1[2], y, skip=cost0)
-        heads, x, pre1, post = [], cost0, None, None
+        c_forks = ops.fork(cost0, self.HOURGLASSES + 1)     # first hourglass + one residual add per hourglass
+        heads, x, pre1, post = [], c_forks[0], None, None
         for i in range(self.HOURGLASSES):
-            out, pre, post = getattr(self, f"dres{i + 2}")(x, pre1 if i > 0 else None, post, residual=cost0)
+            out, pre, post = getattr(self, f"dres{i + 2}")(x, pre1 if i > 0 else None, post, residual=c_forks[i + 1])
             if i == 0:
                 pre1 = pre
             clf = getattr(self, f"classif{i + 1}")

@@ -136,6 +136,11 @@ long long ecm_conv_wino_packed_floats(int Ci, int Co, int kd);
 int ecm_conv_wino_pack_weight(const float* w, float* packed, int Co, int Ci, int kd, int flip_transpose, void* stream);
 int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int Ci, int Co, int D, int H, int W, int kd,
                       void* stream);
+/* out = ((a + b) + c) + d elementwise over n floats, c and d optional (NULL): the gradient accumulation of a tensor with
+ * several consumers in one pass (cmfsm.py:686-693: cost0 feeds the first hourglass and three residual adds) instead of
+ * autograd's chain of binary adds.  16-byte aligned pointers; out may alias an input. */
+int ecm_sum_n(const float* a, const float* b, const float* c, const float* d, float* out, long long n, void* stream);
+
 /* y = conv(x) + addend, addend shaped like y and added in the kernel's epilogue: with the data-gradient weights this is
  * autograd's accumulation at a skip connection (gx = dgrad(gy) + g_skip; BasicBlock cmfsm.py:76-85, dres1 612-613, the
  * hourglass / classifier inputs 636-660) without the separate elementwise pass.  y may not alias addend. */

@@ -762,6 +762,24 @@ def test_winograd_wgrad2d_vs_torch(ecm, B, Ci, Co, H, W):
     close(got, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))
 
 
+@pytest.mark.parametrize("n,numel", [(2, 1000), (3, 4099), (4, 2 * 32 * 6 * 9 * 17), (6, 515)])
+def test_fork_sums_consumer_gradients_in_one_pass(ecm, n, numel):
+    """ops.fork: a tensor with n consumers (cost0: first hourglass + three residual adds, cmfsm.py:686-693); the consumers'
+    gradients are added by ecm_sum_n in the fixed order ((g0 + g1) + g2) + g3 -- bit-identical to that torch expression."""
+    x = dev(seeded("fs.x", numel)).requires_grad_()
+    gs = [dev(seeded(f"fs.g{k}", numel)) for k in range(n)]
+    parts = ecm.ops.fork(x, n)
+    assert all(p.data_ptr() == x.data_ptr() for p in parts)
+    sum((p * g).sum() for p, g in zip(parts, gs)).backward()
+    want = gs[0].clone()
+    if n <= 4:
+        for g in gs[1:]:
+            want = want + g
+        assert torch.equal(x.grad, want)
+    else:
+        close(x.grad, sum(g.double() for g in gs).float(), 1e-6, 1e-6)
+
+
 @pytest.mark.parametrize("shape,Co", [((2, 32, 5, 7, 70), 32), ((1, 64, 3, 9, 33), 64), ((1, 32, 20, 64), 32), ((2, 64, 33, 50), 64),
                                       ((1, 128, 4, 12, 20), 128)])
 def test_fork_folds_skip_gradient_into_data_gradient(ecm, shape, Co):

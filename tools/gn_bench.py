@@ -26,7 +26,8 @@ def timeit(fn, iters=10, warm=3):
 
 def main():
     dev = torch.device("cuda:0")
-    for B, Cc, dims in [(4, 32, (48, 144, 240)), (4, 64, (24, 72, 120)), (8, 32, (1, 576, 960)), (8, 128, (1, 144, 240))]:
+    for B, Cc, dims in [(4, 32, (48, 144, 240)), (4, 64, (24, 72, 120)), (4, 64, (12, 36, 60)), (8, 32, (1, 288, 480)),
+                        (8, 64, (1, 144, 240)), (8, 128, (1, 144, 240)), (8, 32, (1, 144, 240))]:
         x = torch.randn(B, Cc, *dims, device=dev)
         gm, bt = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
         S = x.numel() // (B * Cc)

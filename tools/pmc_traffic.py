@@ -12,7 +12,9 @@ usage: pmc_traffic.py D > profiles/r02_pmc_traffic.json
 Calibration: tools/micro/fetch_calib streams a known byte count once from a 1 GiB buffer with each access shape; factor =
 known bytes / (counter * 1024).  The conv kernels stage their halo tiles with 4-byte-per-lane buffer loads in rows of 34
 floats, so their FETCH_SIZE is scaled by the `read_b32_rows` factor computed against the 128-B lines those rows touch (the
-memory system moves whole lines); 16-byte-per-lane streams (cost volume, GroupNorm) use the `read_b128_*` factor."""
+memory system moves whole lines); 16-byte-per-lane streams (cost volume, GroupNorm) use the `read_b128_*` factor; the Winograd
+convolution's 8-byte pair loads are contiguous across the lanes and take the coalesced `read_b32_buffer` factor (all
+coalesced widths calibrate to the same 2.0)."""
 import collections
 import csv
 import glob
@@ -65,7 +67,8 @@ def main():
     for key, sub, dirs, ffac, alg in (
             ("conv3d_k3_mfma_32to32_B4", "conv3d_k3_mfma", ("conv_fetch", "conv_write"), fac.get("read_b32_rows", 1.0),
              2 * 4 * 32 * 48 * 144 * 240 * 4),
-            ("conv_wino_mfma_32to32_B4", "conv_wino_mfma", ("wino_fetch", "wino_write"), fac.get("read_b32_rows", 1.0),
+            # the Winograd kernel fetches its patches as 8-byte pairs contiguous across the lanes: the coalesced factor
+            ("conv_wino_mfma_32to32_B4", "conv_wino_mfma", ("wino_fetch", "wino_write"), fac.get("read_b32_buffer", 2.0),
              2 * 4 * 32 * 48 * 144 * 240 * 4),
             ("conv3d_wgrad_wino_32to32_B4", "conv3d_wgrad_mfma", ("ww_fetch", "ww_write"), fac.get("read_b32_rows", 1.0),
              2 * 4 * 32 * 48 * 144 * 240 * 4),

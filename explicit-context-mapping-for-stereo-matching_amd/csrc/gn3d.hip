@@ -471,9 +471,8 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
 }
 
 // MASK: 0 = no ReLU, 1 = mask from the forward output y, 2 = mask recomputed as fma(x, a, sh) > 0 (forward without skip)
-// GSKIP: 0 = none, 1 = write the masked gradient to gskip, 2 = ACCUMULATE it into gskip (gskip += g: the residual's
-// gradient joins a gradient that is already there, e.g. cost0's fan-out to dres1 and the three hourglass residuals,
-// cmfsm.py:685-693, so no separate add kernel runs).
+// GSKIP: 0 = none, 1 = write the masked gradient to gskip (the residual operand's gradient; where several gradients meet
+// at one tensor they are summed by ecm_sum_n or in a data-gradient epilogue, see ops.fork / ops._fork_out).
 template <int MASK, int GSKIP>
 __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const float* __restrict__ x, const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -529,11 +528,6 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
                 if (!(__builtin_fmaf(xx.w, a, sh) > 0.f)) gg.w = 0.f;
             }
             if (GSKIP == 1) slice_st(kr, toff + j * 1024, gg);
-            if (GSKIP == 2) {
-                float4 k = slice_ld(kr, toff + j * 1024);
-                k.x += gg.x; k.y += gg.y; k.z += gg.z; k.w += gg.w;
-                slice_st(kr, toff + j * 1024, k);
-            }
             // keep xhat (x itself is not needed again).  Past the slice x reads 0 => xhat = -mean*rstd, but g = 0 there.
             xx.x = (xx.x - mean) * rstd; xx.y = (xx.y - mean) * rstd;
             xx.z = (xx.z - mean) * rstd; xx.w = (xx.w - mean) * rstd;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     // The 4x4 patch is fetched as 8 pairs of neighbouring columns (8-byte loads, contiguous across the lanes): pair A =
     // columns (ow-1, ow), pair B = (ow+1, ow+2) of rows oh-1..oh+2.  Rows / planes outside the volume get the out-of-range
     // offset (hardware zero fill).  A pair never straddles the end of a row: at the left border pair A is read one column to
-    // the right, at the right border pair B one column to the left, and `fix_edges` moves the values into place.
+    // the right, at the right border pair B one column to the left, and transform_rows moves the values into place.
     unsigned poff[8];
     const int n_t = n0 + pr * 32 + l31;                      // this thread's tile; past the last one: everything out of range
     const int trow_t = n_t / tiles_wt;

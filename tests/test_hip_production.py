@@ -250,18 +250,20 @@ def test_heads_backward_576x960(ecm):
 
 
 # ------------------------------------------------------------------------------ (e) one batch-4 training step, both forms
-def test_train_step_b4_collapsed_vs_explicit(ecm):
-    """One cmfsm training step (train.py:162-181) at BASELINE cfg 2 -- batch 4, 576x960, D=192 -- with the cost volume
-    collapsed into 2-D convolutions (default) and with the reference's explicit op sequence: same loss, same gradient for
-    EVERY parameter (whole-tensor bound)."""
+@pytest.mark.parametrize("B,H,W", [(4, 576, 960), (1, 384, 1248)])
+def test_train_step_b4_collapsed_vs_explicit(ecm, B, H, W):
+    """One cmfsm training step (train.py:162-181) at BASELINE cfg 2 -- batch 4, 576x960, D=192 -- and at the KITTI frame of
+    cfg 4 (375x1242 padded to 384x1248, one pair per GPU: 312 / 156 / 78 columns at the three scales of the aggregation
+    stack, none a multiple of a tile width) -- with the cost volume collapsed into 2-D convolutions (default) and with the
+    reference's explicit op sequence: same loss, same gradient for EVERY parameter (whole-tensor bound)."""
     from importlib import import_module
     mdl = import_module("explicit-context-mapping-for-stereo-matching_amd.models")
     dist = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
     torch.manual_seed(0)
     model = ecm.get_model("cmfsm").cuda().train()
     g = torch.Generator(device="cpu").manual_seed(1234)
-    left, right = torch.randn(4, 3, 576, 960, generator=g).cuda(), torch.randn(4, 3, 576, 960, generator=g).cuda()
-    gt = (torch.rand(4, 576, 960, generator=g) * 191.0).cuda()
+    left, right = torch.randn(B, 3, H, W, generator=g).cuda(), torch.randn(B, 3, H, W, generator=g).cuda()
+    gt = (torch.rand(B, H, W, generator=g) * 191.0).cuda()
     res = {}
     prev = mdl.EXPLICIT_COST_VOLUME
     try:

@@ -157,7 +157,7 @@ __device__ __forceinline__ void wg_tile_wino(const float* __restrict__ gaw, cons
     };
     // The k-step loop stays ROLLED (fully unrolled, hipcc's register allocation of 16 x 24 MFMAs with the interleaved
     // prefetch spills ~200 registers); the next tile's global loads are issued in NPH bursts between groups of k-steps.
-    constexpr int NPH = 4, KPP = KS / NPH, LPP = (NLOADS + NPH - 2) / (NPH - 1);   // bursts in the first NPH-1 phases
+    constexpr int NPH = 8, KPP = KS / NPH, LPP = (NLOADS + NPH - 2) / (NPH - 1);   // bursts in the first NPH-1 phases
     constexpr int KUNROLL = KD == 1 ? 8 : 1;   // 2-D: 4 MFMAs per k-step -- a whole phase unrolled (loop control and address
                                                 // arithmetic gone: -6..-12 %); 3-D: 24 per k-step, and unrolling by 2 already spills
     static_assert(KS % NPH == 0, "k-steps split into phases");

@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
         posoff[j] = ok ? (unsigned)(gz * (int)HWi + gy * W + gx) * 4u : 0x80000000u;
     }
     const unsigned plane_bytes = (unsigned)DHWi * 4u;
-    auto prefetch = [&](int c0, float* wdst) {
-        // weight slice: global -> LDS directly (global_load_lds_dwordx4: no VGPRs, lands at wave base + lane*16)
+    auto prefetch = [&](int c0, float* wdst) {                // the chunk's weight slice
+        // global -> LDS directly (global_load_lds_dwordx4: no VGPRs, lands at wave base + lane*16)
 #pragma unroll
         for (int i = 0; i < NWQ; ++i) {
             const int e = tid + i * 256;
@@ -132,16 +132,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wdst + (wave_u * 64 + i * 256) * 4), 16, 0, 0);
             }
         }
-#pragma unroll
-        for (int cc = 0; cc < CIC; ++cc) {
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(c0 + cc) * DHWi), 0,
-                                                                plane_bytes, 0x00020000);
-#pragma unroll
-            for (int j = 0; j < PP; ++j)
-                xr[cc * PP + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, posoff[j], 0, 0));
-        }
+    };
+    // the halo loads of a chunk, one at a time (i = cc * PP + j): inside the MFMA loop they are issued a few per tap --
+    // issued as one burst they fill the memory pipeline's queue and the wave sits on it with the matrix core idle
+    auto prefetch_x = [&](int c0, int i) {
+        const int cc = i / PP, j = i % PP;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(c0 + cc) * DHWi), 0, plane_bytes,
+                                                            0x00020000);
+        xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, posoff[j], 0, 0));
     };
     prefetch(0, Ws);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) prefetch_x(0, i);
     CV_T(0);
     int buf = 0;
     for (int c0 = 0; c0 < Ci; c0 += CIC, buf ^= 1) {
@@ -159,12 +161,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
         __syncthreads();
         CV_T(3);
         const float* Wc = Ws + buf * Cfg::WS_FLOATS;
-        if (c0 + CIC < Ci) prefetch(c0 + CIC, Ws + (buf ^ 1) * Cfg::WS_FLOATS);   // in flight during the MFMA loop below
+        const bool more = c0 + CIC < Ci;
+        if (more) prefetch(c0 + CIC, Ws + (buf ^ 1) * Cfg::WS_FLOATS);            // weights: in flight during the MFMA loop below
         CV_T(4);
+        constexpr int LPT = (NX + NTAPS - 1) / NTAPS;                              // halo loads per tap
         // ---- 27 * CIC/2 k-steps ---------------------------------------------------------------
 #pragma unroll
         for (int tap = 0; tap < NTAPS; ++tap) {
             const int kd = KD == 3 ? tap / 9 : 0, kh = (tap / 3) % 3, kw = tap % 3;
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < LPT; ++q)
+                    if (tap * LPT + q < NX) prefetch_x(c0 + CIC, tap * LPT + q);
+            }
 #pragma unroll
             for (int kk = 0; kk < CIC / 2; ++kk) {
                 float a[CO_TILES];

@@ -96,16 +96,18 @@ __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float
                 __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(wdst + (wave_u * 64 + i * NTHR) * 4), 16, 0, 0);
             }
         }
-#pragma unroll
-        for (int cc = 0; cc < CIC; ++cc) {
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(c0 + cc) * DHWi), 0,
-                                                                plane_bytes, 0x00020000);
-#pragma unroll
-            for (int j = 0; j < PP; ++j)
-                xr[cc * PP + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, posoff[j], 0, 0));
-        }
+    };
+    // the halo loads of a chunk one at a time (i = cc * PP + j), issued a few per tap inside the MFMA loop (see conv3d.hip)
+    constexpr int NX = CIC * PP;
+    auto prefetch_x = [&](int c0, int i) {
+        const int cc = i / PP, j = i % PP;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)(c0 + cc) * DHWi), 0, plane_bytes,
+                                                            0x00020000);
+        xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, posoff[j], 0, 0));
     };
     prefetch(0, Ws);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) prefetch_x(0, i);
     int buf = 0;
     for (int c0 = 0; c0 < Ci; c0 += CIC, buf ^= 1) {
         __syncthreads();
@@ -119,9 +121,16 @@ __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float* Wc = Ws + buf * Cfg::WS_FLOATS;
-        if (c0 + CIC < Ci) prefetch(c0 + CIC, Ws + (buf ^ 1) * Cfg::WS_FLOATS);
+        const bool more = c0 + CIC < Ci;
+        if (more) prefetch(c0 + CIC, Ws + (buf ^ 1) * Cfg::WS_FLOATS);
+        constexpr int LPT = (NX + NTAPS - 1) / NTAPS;
 #pragma unroll
         for (int tap = 0; tap < NTAPS; ++tap) {
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < LPT; ++q)
+                    if (tap * LPT + q < NX) prefetch_x(c0 + CIC, tap * LPT + q);
+            }
             // tap k of an output of parity p reads input m + (k == 0 ? 1 : 0); k == 1 <-> even output, k in {0,2} <-> odd
             const int kd = KD == 3 ? tap / 9 : 1, kh = (tap / 3) % 3, kw = tap % 3;
             const int pd = kd != 1, ph = kh != 1, pw = kw != 1;

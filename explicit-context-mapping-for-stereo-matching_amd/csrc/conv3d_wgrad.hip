@@ -157,7 +157,9 @@ __device__ __forceinline__ void wg_tile_wino(const float* __restrict__ gaw, cons
     };
     // The k-step loop stays ROLLED (fully unrolled, hipcc's register allocation of 16 x 24 MFMAs with the interleaved
     // prefetch spills ~200 registers); the next tile's global loads are issued in NPH bursts between groups of k-steps.
-    constexpr int NPH = 8, KPP = KS / NPH, LPP = (NLOADS + NPH - 2) / (NPH - 1);   // bursts in the first NPH-1 phases
+    // Burst length matters: a long burst fills the memory pipeline's queue and the wave sits on it with the matrix core idle
+    // (3-D: 3 bursts of 43 loads -> 7 of 19: 1.95 -> 1.69 ms; one per k-step would need the loop unrolled, which spills).
+    constexpr int NPH = KD == 1 ? 16 : 8, KPP = KS / NPH, LPP = (NLOADS + NPH - 2) / (NPH - 1);   // bursts in the first NPH-1 phases
     constexpr int KUNROLL = KD == 1 ? 8 : 1;   // 2-D: 4 MFMAs per k-step -- a whole phase unrolled (loop control and address
                                                 // arithmetic gone: -6..-12 %); 3-D: 24 per k-step, and unrolling by 2 already spills
     static_assert(KS % NPH == 0, "k-steps split into phases");

@@ -454,7 +454,10 @@ int launch_wino(const float* x, const float* up, const float* addend, float* y, 
     const int tblocks = (ntile + 32 * TR - 1) / (32 * TR);
     const long long nblk = (long long)B * tiles_d * tblocks;
     const int groups = (Co + 31) / 32, nchunks = (Ci + CIC - 1) / CIC;
-    if (nblk > 0x7fffffffLL || groups > 65535 || (long long)D * H * W * 4 >= 0x80000000LL) return ECM_EUNSUP;
+    // the epilogue's store / addend descriptors span 32 channels (num_records = 32 planes' bytes, offsets col*plane_bytes + yoff,
+    // 0x80000000 as the dropped-store sentinel): all 32-bit arithmetic, so 32 planes must fit below 2^31 bytes -- the same
+    // bound as ecm_conv_wino_wgrad
+    if (nblk > 0x7fffffffLL || groups > 65535 || (long long)D * H * W * 4 * 32 > 0x80000000LL) return ECM_EUNSUP;
     auto kern = conv_wino_mfma<KD, TD, TR, CIC>;
     const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     if (e != hipSuccess) return (int)e;

@@ -86,6 +86,7 @@ class FlatBucketDDP:
             p.grad = v
         self._sum_only = False
         self._early_work = None
+        self._armed = False
         self._fired = 0
         self._expected = None
         self._side = torch.cuda.Stream(device=ref.device) if ref.is_cuda else None
@@ -96,25 +97,38 @@ class FlatBucketDDP:
             self.broadcast_parameters()
 
     def broadcast_parameters(self, src: int = 0):
-        for t in list(self.module.parameters()) + list(self.module.buffers()):
-            dist.broadcast(t.data, src)
+        """In-place on the tensors themselves under no_grad (the version counters move, unlike a `.data` write), and any
+        packed weight layout cached by ops.frozen_weights() is dropped."""
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                dist.broadcast(t, src)
+        from . import ops
+        ops.invalidate_packed()
 
     def zero_grad(self):
+        """Start of a step: drops the gradients and ARMS the early all-reduce for exactly one backward.  Gradient
+        accumulation (several backwards before allreduce_gradients()) or a second backward over a retained graph therefore
+        never start a collective over a bucket that later backwards still write: only the first backward after zero_grad()
+        may fire it, and once it has fired any further backward of the step is refused."""
         for p in self.params:
             p.grad = None
+        self._armed = True
 
     # ---- loss scaling --------------------------------------------------------------------------------------------
     def global_mean_loss(self, loss: torch.Tensor, count: torch.Tensor):
         """loss = this rank's masked MEAN, count = its number of masked elements (device scalar, e.g. stereo_loss3's
         metrics[1]).  Returns the loss rescaled so that summing gradients over ranks gives the gradient of the masked mean
-        over the GLOBAL batch.  A rank with an empty mask contributes nothing."""
+        over the GLOBAL batch.  A rank with an empty mask contributes nothing, and a step whose mask is empty on EVERY rank
+        has loss 0 with zero (not NaN) gradients.  Contract: every rank calls this in every step it calls
+        allreduce_gradients() in (it holds a collective, and switches that step's reduction from average to sum)."""
         if self.world == 1:
             return loss
         count = count.detach().to(loss.dtype)
         total = count.clone()
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
         self._sum_only = True
-        return torch.where(count > 0, loss * (count / total), torch.zeros_like(loss))
+        scale = count / total.clamp_min(1.0)          # total == 0 => count == 0 => scale 0 (never 0/0)
+        return torch.where(count > 0, loss, torch.zeros_like(loss)) * scale
 
     # ---- overlap ---------------------------------------------------------------------------------------------------
     def _watch_late_outputs(self, _module, _inputs, outputs):
@@ -126,9 +140,16 @@ class FlatBucketDDP:
                 t.register_hook(self._late_output_grad)
 
     def _late_output_grad(self, grad):
+        if self._early_work is not None:
+            raise RuntimeError("FlatBucketDDP: a backward pass ran after the early all-reduce of this step had started "
+                               "(gradient accumulation / retain_graph): construct with late_module=None or call "
+                               "allreduce_gradients() once per backward")
         self._fired += 1
-        if self._expected is not None and self._fired == self._expected and self._early_work is None:
+        if self._armed and self._expected is not None and self._fired == self._expected:
+            self._armed = False
             self._start_early()
+        elif self._expected is not None and self._fired > self._expected:
+            self._armed = False                       # a second backward in this step: no early start, reduce at the end
         return grad
 
     def _gather(self, lo: int, hi: int):
@@ -175,9 +196,9 @@ class FlatBucketDDP:
                 self.flat.div_(self.world)
         for p, v in zip(self.params, self.views):
             p.grad = v
-        if self.overlap:
-            self._expected = self._fired if self._fired > 0 else None      # hooks per backward, learnt from this step
-        self._fired, self._early_work, self._sum_only = 0, None, False
+        if self.overlap and self._expected is None and self._fired > 0:
+            self._expected = self._fired              # hooks per backward, learnt from the first step (one backward per step)
+        self._fired, self._early_work, self._sum_only, self._armed = 0, None, False, False
 
     def __call__(self, *a, **k):
         return self.module(*a, **k)
@@ -200,9 +221,11 @@ def masked_smooth_l1_x3_with_count(preds, gt, maxdisp: int = 192):
 
 class GraphedForward:
     """Inference through one captured HIP graph: the eval forward of a model is a fixed sequence of ~400 kernel launches
-    (encoder on MIOpen + the hot path's kernels), which at batch 1 is partly launch-bound; capturing it once and replaying
-    it removes the per-launch host cost.  Inputs are copied into the graph's static buffers; the returned tensors are the
-    graph's static outputs (valid until the next call).  Shapes are fixed at construction."""
+    (encoder + hot path, all on this library's kernels), which at batch 1 is partly launch-bound; capturing it once and
+    replaying it removes the per-launch host cost.  The weight-packing kernels are captured too (ops._cached_pack never
+    serves a cached layout during capture), so a replay follows in-place weight updates such as a later
+    `load_state_dict` into the same model.  Inputs are copied into the graph's static buffers; the returned tensors are
+    the graph's static outputs (valid until the next call).  Shapes are fixed at construction."""
 
     def __init__(self, model: torch.nn.Module, left: torch.Tensor, right: torch.Tensor, warmup: int = 3):
         assert left.is_cuda and right.is_cuda, "GraphedForward captures a HIP graph: GPU tensors only"
@@ -210,8 +233,8 @@ class GraphedForward:
         self.left, self.right = left.clone(), right.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():      # warm-up outside capture: lazy one-time work (MIOpen solver
-            for _ in range(warmup):                          # picks, LDS attributes, occupancy queries, constant masks)
+        with torch.cuda.stream(side), torch.no_grad():      # warm-up outside capture: lazy one-time work (LDS attributes,
+            for _ in range(warmup):                          # occupancy queries, constant masks, allocator growth)
                 self.model(self.left, self.right)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()

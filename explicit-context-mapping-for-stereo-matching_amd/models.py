@@ -286,7 +286,7 @@ class feature_extraction(nn.Module):
         layer4, cmfsm.py:150), run it on d*d phase planes, where the convolutions are ordinary 3x3 ones (ops.phase_split)."""
         convs = [m for m in layer.modules() if isinstance(m, nn.Conv2d)]
         d = convs[0].dilation[0]
-        ok = (ops.WINOGRAD and d > 1 and x.shape[-2] % d == 0 and x.shape[-1] % d == 0
+        ok = (ops.WINOGRAD and d > 1 and x.shape[-2] % d == 0 and x.shape[-1] % d == 0 and x.shape[-1] // d >= 2
               and all(m.kernel_size == (3, 3) and m.stride == (1, 1) and m.dilation == (d, d) and m.padding == (d, d) for m in convs))
         if not ok:
             return layer(x)

@@ -1,0 +1,98 @@
+"""Packed-weight layouts must follow EVERY kind of weight update: optimizer steps, load_state_dict, and
+in-place writes through `.data` that the version counter does not see -- eagerly, under a captured HIP graph, and inside
+the explicit ops.frozen_weights() opt-in (where `.data` writes need ops.invalidate_packed())."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ecm():
+    assert torch.cuda.is_available()
+    import ecm_amd
+    return ecm_amd
+
+
+def _inputs(seed=0, h=256, w=256):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(1, 3, h, w, device="cuda", generator=g), torch.randn(1, 3, h, w, device="cuda", generator=g)
+
+
+def _perturbed_state(model, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return {k: v + 0.05 * v.abs().mean() * torch.randn(v.shape, device=v.device, generator=g) for k, v in model.state_dict().items()}
+
+
+def test_data_write_is_seen_by_the_next_forward(ecm):
+    torch.manual_seed(1)
+    model = ecm.get_model("cmfsm").cuda().eval()
+    left, right = _inputs()
+    with torch.no_grad():
+        before = model(left, right)[2].clone()
+        new = _perturbed_state(model, 5)
+        for k, p in model.named_parameters():
+            p.data.copy_(new[k])                           # does NOT bump p._version
+        got = model(left, right)[2].clone()
+        fresh = ecm.get_model("cmfsm").cuda().eval()
+        fresh.load_state_dict(new)
+        want = fresh(left, right)[2]
+    assert not torch.equal(before, got)
+    assert torch.equal(got, want)
+
+
+def test_frozen_weights_reuses_and_invalidates(ecm):
+    ops = ecm.ops
+    torch.manual_seed(2)
+    conv = torch.nn.Conv3d(32, 32, 3, padding=1, bias=False).cuda()
+    x = torch.randn(1, 32, 6, 10, 12, device="cuda")
+    with torch.no_grad(), ops.frozen_weights():
+        y0 = ops.conv3d_k3(x, conv.weight, 1)
+        assert getattr(conv.weight, "_ecm_packed", None), "inside frozen_weights() the packed layout is cached"
+        packed = conv.weight._ecm_packed["w3"][1]
+        ops.conv3d_k3(x, conv.weight, 1)
+        assert conv.weight._ecm_packed["w3"][1] is packed                      # reused
+        conv.weight.mul_(2.0)                                                  # version counter moves: re-packed
+        y1 = ops.conv3d_k3(x, conv.weight, 1)
+        torch.testing.assert_close(y1, 2.0 * y0, rtol=1e-5, atol=1e-6)
+        conv.weight.data.mul_(0.5)                                             # invisible to the version counter ...
+        ops.invalidate_packed()                                                # ... so the contract asks for this
+        y2 = ops.conv3d_k3(x, conv.weight, 1)
+        torch.testing.assert_close(y2, y0, rtol=1e-5, atol=1e-6)
+    with torch.no_grad():                                                       # outside: never cached
+        conv.weight.data.mul_(3.0)
+        y3 = ops.conv3d_k3(x, conv.weight, 1)
+    torch.testing.assert_close(y3, 3.0 * y0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(y0, F.conv3d(x, conv.weight / 3.0, None, 1, 1), rtol=1e-3, atol=1e-4)
+
+
+def test_graph_replay_follows_load_state_dict(ecm):
+    from importlib import import_module
+    D = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
+    torch.manual_seed(3)
+    model = ecm.get_model("cmfsm").cuda().eval()
+    left, right = _inputs(7)
+    graphed = D.GraphedForward(model, left, right)
+    a = graphed(left, right)[2].clone()
+    new = _perturbed_state(model, 9)
+    model.load_state_dict(new)                             # test.py's checkpoint loop: same model object, new weights
+    b = graphed(left, right)[2].clone()
+    with torch.no_grad():
+        want = model(left, right)[2]
+    assert not torch.equal(a, b)
+    assert torch.equal(b, want)
+
+
+def test_winograd_range_check_at_the_descriptor_bound(ecm):
+    """ecm_conv_wino_fwd addresses 32 channel planes with 32-bit byte offsets: a plane set above 2^24 elements is refused
+    (ECM_EUNSUP) instead of wrapping, and ops routes such a volume to the direct kernel."""
+    lib = ecm._lib
+    import ctypes as C
+    x = torch.zeros(16, device="cuda")
+    D, H, W = 65, 512, 512                                  # 17.0 M elements per channel > 2^24
+    with pytest.raises(RuntimeError, match="not supported"):
+        lib.call("ecm_conv_wino_fwd", C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), 1, 32, 32,
+                 D, H, W, 3, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert not ecm.ops._wino_ok(torch.empty(0, 32, D, H, W, device="meta"))
+    assert ecm.ops._wino_ok(torch.empty(0, 32, 64, 512, 512, device="meta"))

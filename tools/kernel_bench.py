@@ -27,11 +27,16 @@ def timeit(fn, iters=10, warm=3):
     return s.elapsed_time(e) / iters
 
 
-def report(name, ms, gbytes=None, gflop=None):
+def report(name, ms, gbytes=None, gflop=None, executed=1.0):
+    """executed: fraction of the direct-count FLOPs the kernel issues on the matrix cores (Winograd F(2x2,3x3) x direct
+    depth: 12/27 in 3-D, 16/36 in 2-D); the roofline fraction is on EXECUTED work, the direct count is printed beside it."""
     extra = ""
     if gbytes:
         extra += f"  {gbytes / ms:8.1f} GB/s ({gbytes / ms / 8000 * 100:.1f}% of 8 TB/s)"
-    if gflop:
+    if gflop and executed != 1.0:
+        extra += (f"  {gflop * executed / ms:8.2f} TFLOP/s executed ({gflop * executed / ms / 157.3 * 100:.1f}% of 157.3)"
+                  f"  [{gflop / ms:7.2f} TF direct-count equivalent]")
+    elif gflop:
         extra += f"  {gflop / ms:8.2f} TFLOP/s ({gflop / ms / 157.3 * 100:.1f}% of 157.3)"
     print(f"{name:44s} {ms:9.3f} ms{extra}", flush=True)
 
@@ -73,7 +78,11 @@ def main():
                 type("c", (), {"saved_tensors": (xg, wt), "stride": 1, "needs_input_grad": (False, True, False)}), gyc)),
                 gbytes=(x.numel() + x.numel() // ci) * 4 / 1e6)
             continue
-        report(f"conv3d {label} {ci}->{co} s{st} {dims}", timeit(lambda: ops._conv_fwd(x, pk, co, st)), gflop=gf)
+        report(f"conv3d {label} {ci}->{co} s{st} {dims} (direct)", timeit(lambda: ops._conv_fwd(x, pk, co, st)), gflop=gf)
+        if st == 1 and ops.WINOGRAD:
+            pkw = ops._wino_pack(wt, 3, False)
+            report(f"conv3d {label} {ci}->{co} s{st} {dims} (Winograd)", timeit(lambda: ops._wino_run(x, pkw, co, 3)), gflop=gf,
+                   executed=12.0 / 27.0)
     for (ci, co, dims, label) in [(64, 64, (12, 36, 60), "hg.conv5"), (64, 32, (24, 72, 120), "hg.conv6")]:
         x = torch.randn(B, ci, *dims, device=dev)
         wt = torch.randn(ci, co, 3, 3, 3, device=dev) * 0.05
@@ -88,7 +97,9 @@ def main():
         od = [(d - 1) // st + 1 for d in dims]
         gy = torch.randn(B, co, *od, device=dev)
         gf = 2.0 * 27 * ci * co * od[0] * od[1] * od[2] * B / 1e9
-        report(f"{label} {ci}->{co} s{st} {dims}", timeit(lambda: ops._wgrad(x, gy, co, ci, st)), gflop=gf)
+        wino = st == 1 and ops.WINOGRAD and ops.WINOGRAD_WGRAD
+        report(f"{label} {ci}->{co} s{st} {dims}" + (" (Winograd)" if wino else ""), timeit(lambda: ops._wgrad(x, gy, co, ci, st)),
+               gflop=gf, executed=12.0 / 27.0 if wino else 1.0)
     del x, gy
     x = torch.randn(B, 32, D, h, w, device=dev)
     gm, bt = torch.ones(32, device=dev), torch.zeros(32, device=dev)
@@ -118,7 +129,7 @@ def main():
     with torch.no_grad():
         lr_l, _, hr_l = model.feature_extraction(left)
         lr_r, _, _ = model.feature_extraction(right)
-        report("encoder x2 (PyTorch/MIOpen)", timeit(lambda: (model.feature_extraction(left), model.feature_extraction(right)), 5, 2))
+        report("encoder x2 (native 2-D family + GroupNorm; pooling / cat on ATen)", timeit(lambda: (model.feature_extraction(left), model.feature_extraction(right)), 5, 2))
         # 1,069 GFLOP is the reference's op count; the collapsed first conv executes 183 -> ~16 of them,
         # so the rate below is "reference-equivalent", the executed rate is ~16 % lower
         report("hot path fwd (HIP), reference-equivalent FLOPs", timeit(lambda: model.hot_path(lr_l, hr_l, lr_r), 5, 2), gflop=1069)

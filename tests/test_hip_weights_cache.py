@@ -55,15 +55,15 @@ def test_frozen_weights_reuses_and_invalidates(ecm):
         assert conv.weight._ecm_packed["w3"][1] is packed                      # reused
         conv.weight.mul_(2.0)                                                  # version counter moves: re-packed
         y1 = ops.conv3d_k3(x, conv.weight, 1)
-        torch.testing.assert_close(y1, 2.0 * y0, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(y1, 2.0 * y0, rtol=1e-4, atol=1e-5)
         conv.weight.data.mul_(0.5)                                             # invisible to the version counter ...
         ops.invalidate_packed()                                                # ... so the contract asks for this
         y2 = ops.conv3d_k3(x, conv.weight, 1)
-        torch.testing.assert_close(y2, y0, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(y2, y0, rtol=1e-4, atol=1e-5)
     with torch.no_grad():                                                       # outside: never cached
         conv.weight.data.mul_(3.0)
         y3 = ops.conv3d_k3(x, conv.weight, 1)
-    torch.testing.assert_close(y3, 3.0 * y0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(y3, 3.0 * y0, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(y0, F.conv3d(x, conv.weight / 3.0, None, 1, 1), rtol=1e-3, atol=1e-4)
 
 

@@ -1,0 +1,114 @@
+"""End-to-end gradients on an fp64 yardstick.
+
+At random initialisation the parameter gradients of this network are sums of millions of terms with ReLU / LeakyReLU /
+smooth-L1 kinks, so two correct fp32 evaluations differ by a few tenths of a percent.  Instead of accepting "5 % of the
+largest element", the fixtures (tests/golden/make_golden_fp64.py) hold the REFERENCE's own run in fp64 -- the truth -- and
+how far the reference's own fp32 run is from it.  The HIP path must be as close to the truth as another fp32 evaluation
+can be: within K = 4 x the reference-fp32's own distance plus a floor of 1e-3 of the quantity's scale (the floor covers
+parameters where the reference's fp32 run happens to land unusually close)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import ecm_oracle as O
+from oracle.weights import make_state_dict, seeded, tensor_for
+
+pytestmark = pytest.mark.gpu
+K = 4.0
+FLOOR = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ecm():
+    assert torch.cuda.is_available()
+    import ecm_amd
+    return ecm_amd
+
+
+def _z(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _check_params(model, z, label, skip_prefix=None):
+    worst = []
+    n_full = 0
+    for k, p in model.named_parameters():
+        if skip_prefix and k.startswith(skip_prefix):
+            continue
+        kk = k.replace(".", "_")
+        n64, n32 = float(z["gn64_" + kk]), float(z["gn32_" + kk])
+        p64, p32 = float(z["gp64_" + kk]), float(z["gp32_" + kk])
+        g = p.grad.detach().double().cpu() if p.grad is not None else torch.zeros(p.shape, dtype=torch.float64)
+        n_hip = float(g.norm())
+        p_hip = float((g * seeded("proj:" + k, *g.shape).double()).sum())
+        # every parameter: norm and a random projection (a norm cannot see a permuted gradient; the projection can)
+        tol_n = K * abs(n32 - n64) + FLOOR * n64 + 1e-12
+        tol_p = K * abs(p32 - p64) + 2e-2 * n64 + 1e-12          # a projection error is ~ |e| x N(0,1): floor at 2 % of |g|
+        assert abs(n_hip - n64) <= tol_n, f"{label} {k}: |g| {n_hip:.6e} vs fp64 {n64:.6e} (reference fp32 {n32:.6e}); tol {tol_n:.2e}"
+        assert abs(p_hip - p64) <= tol_p, f"{label} {k}: projection {p_hip:.6e} vs fp64 {p64:.6e} (reference fp32 {p32:.6e})"
+        worst.append((abs(n_hip - n64) / max(abs(n32 - n64), FLOOR * n64 / K + 1e-30), k))
+        if "g64_" + kk in z:                                     # full tensors
+            t64 = torch.from_numpy(z["g64_" + kk])
+            e = (g - t64).abs()
+            scale = float(t64.abs().max())
+            rms64 = float(t64.pow(2).mean().sqrt())
+            emax32, erms32 = float(z["e32max_" + kk]), float(z["e32rms_" + kk])
+            assert float(e.max()) <= K * emax32 + FLOOR * scale, \
+                f"{label} {k}: max |hip - fp64| {float(e.max()):.3e} vs the reference fp32's {emax32:.3e} (scale {scale:.3e})"
+            assert float(e.pow(2).mean().sqrt()) <= K * erms32 + FLOOR * rms64, \
+                f"{label} {k}: rms |hip - fp64| {float(e.pow(2).mean().sqrt()):.3e} vs the reference fp32's {erms32:.3e}"
+            n_full += 1
+    return n_full, sorted(worst)[-3:]
+
+
+def test_full_cmfsm_train_step_against_fp64_reference(ecm):
+    """train.py:162-181 on the 256x512 fixture: predictions, loss and EVERY parameter's gradient vs the reference in fp64."""
+    z = _z("g8d_full_cmfsm_256x512_fp64")
+    model = ecm.get_model("cmfsm")
+    model.load_state_dict({k: tensor_for(k, v.shape) for k, v in model.state_dict().items()})
+    model = model.cuda().train()
+    left, right = seeded("g8.left", 1, 3, 256, 512).cuda(), seeded("g8.right", 1, 3, 256, 512).cuda()
+    gt = (torch.rand(1, 256, 512, generator=torch.Generator().manual_seed(8)) * 191.0).cuda()
+    o = model(left, right)
+    loss = O.train_loss(o, gt)
+    loss.backward()
+    for i in (1, 2, 3):
+        d64 = (o[i - 1].detach().double().cpu()[..., ::4, ::4] - torch.from_numpy(z[f"o{i}_64"])).abs()
+        # SURVEY section 7's stated end-to-end tolerance: max 2e-2 px, mean 1e-3 px (disparities span 0..191 px)
+        assert float(d64.max()) <= 2e-2 and float(d64.mean()) <= 1e-3, (i, float(d64.max()), float(d64.mean()))
+    l64, l32 = float(z["loss_64"]), float(z["loss_32"])
+    assert abs(float(loss) - l64) <= K * abs(l32 - l64) + 1e-5 * l64, (float(loss), l64, l32)
+    n_full, worst = _check_params(model, z, "cmfsm")
+    assert n_full >= 14, n_full
+    print("worst norm-error ratios vs the yardstick:", worst)
+
+
+def test_cmfsm_sub_16_hot_path_against_fp64_reference(ecm):
+    """Post-encoder path of cmfsm_sub_16 (six-related weights on both images + the fused volume-mapping head,
+    cmfsm_sub_16.py:722-850): predictions, feature gradients and every parameter's gradient vs the reference in fp64."""
+    arch, s, h, w = "cmfsm_sub_16", 16, 4, 4
+    z = _z(f"arch_{arch}_fp64")
+    model = ecm.get_model(arch)
+    sd = {k: tensor_for(k, v.shape) for k, v in model.state_dict().items() if not k.startswith("feature_extraction")}
+    model.load_state_dict(sd, strict=False)
+    model = model.cuda()
+    feats = [seeded(f"{arch}.{n}", 1, 32, *sz).cuda().requires_grad_() for n, sz in
+             (("lr_l", (h, w)), ("hr_l", (s * h, s * w)), ("lr_r", (h, w)), ("hr_r", (s * h, s * w)))]
+    preds = model.hot_path(*feats)
+    loss = sum((p * seeded(f"{arch}.G{i}", *p.shape).cuda()).sum() for i, p in enumerate(preds))
+    loss.backward()
+    for i, p in enumerate(preds, 1):
+        d = (p.detach().double().cpu() - torch.from_numpy(z[f"pred{i}_64"])).abs()
+        assert float(d.max()) <= 2e-2 and float(d.mean()) <= 1e-3, (i, float(d.max()), float(d.mean()))
+    for nm, t in zip(("g_lr_l", "g_hr_l", "g_lr_r", "g_hr_r"), feats):
+        t64 = torch.from_numpy(z[nm + "_64"])
+        e = (t.grad.double().cpu() - t64).abs()
+        assert float(e.max()) <= K * float(z["e32max_" + nm]) + FLOOR * float(t64.abs().max()), \
+            (nm, float(e.max()), float(z["e32max_" + nm]), float(t64.abs().max()))
+    n_full, worst = _check_params(model, z, arch, skip_prefix="feature_extraction")
+    assert n_full >= 8, n_full
+    print("worst norm-error ratios vs the yardstick:", worst)

@@ -370,10 +370,11 @@ def test_full_model_train_step_golden(ecm, cmfsm_sd):
         assert abs(got - ref) <= 2e-2 * ref + 1e-7, (k, got, ref)
         ref_t = g["g_" + k.replace(".", "_")]                    # full tensor, whole-tensor bound
         err = float((params[k].grad.cpu() - ref_t).abs().max())
-        # whole model incl. the encoder's MIOpen layers (their output differs from the CPU reference by ~3e-4 and run to
-        # run, tools/det_probe.py); cancellation-heavy sums like the ECM MLP's weight gradient amplify that to a few % of
-        # the largest element -- still far below what a permuted or mis-indexed gradient would show
-        assert err <= 5e-2 * float(ref_t.abs().max()) + 1e-9, (k, err, float(ref_t.abs().max()))
+        # a coarse whole-tensor bound against the reference's fp32 run (two fp32 evaluations of this network differ by up
+        # to ~1.5 % of the largest element, see the fixture's own fp32-vs-fp64 distances); the sharp statement -- distance
+        # from the fp64 truth bounded by the reference-fp32's own distance, for EVERY parameter -- is
+        # tests/test_hip_fp64_yardstick.py
+        assert err <= 3e-2 * float(ref_t.abs().max()) + 1e-9, (k, err, float(ref_t.abs().max()))
 
 
 def test_hot_path_explicit_cost_volume_agrees(ecm, cmfsm_sd):
@@ -416,10 +417,8 @@ def test_full_model_golden(ecm, cmfsm_sd):
     for i, name in enumerate(("o1", "o2", "o3")):
         assert o[i].shape == (1, 1, 256, 512)
         d = (o[i].cpu()[..., ::4, ::4] - g[name]).abs()
-        # stated tolerance for the END-TO-END model (disparities span 0..191 px): max 0.02 px, mean 0.0025 px.  The mean is
-        # looser than for the hot path alone (1e-3, above) because the MIOpen encoder in front of it picks its fp32
-        # algorithm (Winograd / implicit GEMM) per box and is not run-to-run deterministic (tests/test_hip_fullsize.py).
-        assert d.max() <= 2e-2 and d.mean() <= 2.5e-3, (name, d.max(), d.mean())
+        # stated tolerance for the END-TO-END model (disparities span 0..191 px): max 0.02 px, mean 0.001 px
+        assert d.max() <= 2e-2 and d.mean() <= 1e-3, (name, d.max(), d.mean())
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 16, 32), (2, 37, 53), (4, 256, 512)])

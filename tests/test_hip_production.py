@@ -281,7 +281,8 @@ def test_train_step_b4_collapsed_vs_explicit(ecm, B, H, W):
     assert la == la and abs(la - lb) <= 1e-4 * abs(lb), (la, lb)
     worst = max(((float((ga[k] - gb[k]).abs().max()) / (float(gb[k].abs().max()) + 1e-30)), k) for k in ga)
     # everything after dres0.0 is the same kernels on inputs that differ by fp32 rounding of the first conv (~1e-6
-    # relative); the encoder's MIOpen layers add their own run-to-run noise (tools/det_probe.py: ~3e-4 on its output)
+    # relative), which kink flips of ReLU / LeakyReLU / smooth-L1 amplify to the per-mille level in single gradient
+    # elements (the fp64 yardstick of the same effect: tests/test_hip_fp64_yardstick.py)
     assert worst[0] <= 2e-2, f"largest relative gradient difference {worst}"
     for k in ("dres0.0.0.weight", "dres0.0.1.weight", "dres1.0.0.weight", "mapping_matrix.similarity1.conv0.weight"):
         rel_close(ga[k], gb[k], 5e-3, k)

@@ -111,6 +111,41 @@ def cpu_baseline(threads: int, H: int, W: int):
             "cost_volume_ms": cv_s * 1e3}
 
 
+def shard_feeder_rate(dev, B, n_frames=32):
+    import tempfile
+    import numpy as np
+    from importlib import import_module
+    S = import_module("explicit-context-mapping-for-stereo-matching_amd.shards")
+    rs = np.random.RandomState(0)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        frames = []
+        base = np.concatenate([rs.randint(0, 256, size=(540, 960, 6)).astype(np.float32),
+                               (rs.rand(540, 960, 1) * 191.0).astype(np.float32)], 2)
+        for i in range(n_frames):                  # distinct frames from one random base (rolled): cheap to make
+            frames.append(np.roll(base, 7 * i, axis=1))
+        path = S.write_shard(frames, os.path.join(d, "bench.ecms"), "fp16")
+        del frames
+        reader = S.ShardReader(path)
+        for key, split, label in (("eval_full_frames", "test", "540x960 frames -> [B,3,576,960] (Flying3d.py:66-72), 8 B/px over PCIe"),
+                                  ("train_crops", "train", "random 256x512 windows (Flying3d.py:51-56): only the window crosses PCIe")):
+            feeder = S.ShardFeeder(reader, B, split=split, device=dev, prefetch=2, shuffle=True)
+            for _ in feeder:                       # warm-up epoch: page cache, pinned buffers, allocator
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 0
+            for _ in range(3):
+                for batch in feeder:
+                    n += B
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[key] = {"value": n / dt, "unit": "pairs/s", "pairs": n, "seconds": dt, "workload": label}
+            feeder.close()
+        out["shard"] = {"frames": n_frames, "bytes": os.path.getsize(path), "disparity": "fp16"}
+    return out
+
+
 def _timed(fn, steps, warmup, sync):
     for _ in range(warmup):
         fn()
@@ -302,6 +337,14 @@ def main():
         note(f"cfg5 cost volume: {ms5:.3f} ms")
         del f5l, f5r
         ops.check_async_errors()
+        # n4: the packed-shard feeder (memory map -> pinned buffer -> copy stream -> ecm_frame_prep_packed), alone, on a
+        # synthetic shard of 960x540 frames: sustained pairs/s next to the step's pairs/s (it must stay ahead of it)
+        try:
+            configs["n4_shard_feeder"] = shard_feeder_rate(dev, B)
+            note(f"shard feeder: {configs['n4_shard_feeder']['eval_full_frames']['value']:.0f} pairs/s full frames, "
+                 f"{configs['n4_shard_feeder']['train_crops']['value']:.0f} pairs/s training crops")
+        except OSError as e:                       # no scratch space on this box: report, do not fail the bench line
+            configs["n4_shard_feeder"] = {"error": str(e)}
 
     if rank == 0:
         h, w, Dl = H // 4, W // 4, D // 4

@@ -319,6 +319,37 @@ def main():
              f"{configs['cfg1_eval_forward_b4']['value']:.1f} pairs/s at B={B}")
         model.train()
         del l1, r1, g1, lb, rb
+        # the other head families at production size, eval forward as test.py runs it (its default --arch is
+        # bilinear_cmf_sub_16, test.py:111): trilinear head (a11) and volume-mapping head (a10), with the head kernel
+        # event-timed on the launch stream.  Both heads are bound by fp32 exp / FMA issue over H*W*192 logits per head, not by
+        # HBM (they read < 1 MB of LR logits and ~20 MB of weight planes): achieved_GBs is on record, the bound is VALU.
+        for arch, entry, label in (("bilinear_cmf_sub_16", "ecm_trilinear_softargmin_fwd", "trilinear head (bilinear_cmf.py:447-471)"),
+                                   ("cmfsm_sub_16", "ecm_volume_mapping_fwd", "volume-mapping head (cmfsm_sub_16.py:767-848)")):
+            torch.manual_seed(0)
+            m2 = ecm_amd.get_model(arch).to(dev).eval()
+            lv, rv, _ = make_inputs(1, H, W, 80)
+
+            def eval_v():
+                with torch.no_grad():
+                    return m2(lv, rv)[2]
+            with ops.frozen_weights():
+                ms = _timed(eval_v, 10, 3, sync) * 1e3
+                lib.enable_timer(entry)
+                for _ in range(5):
+                    eval_v()
+                sync()
+                ev = lib.disable_timers()[entry]
+            head_ms = sum(s_.elapsed_time(e_) for s_, e_, _ in ev) / len(ev)
+            nlog = 3 * H * W * D                                     # logits evaluated by the fused head (3 heads)
+            configs[f"eval_forward_b1_{arch}"] = {
+                "ms_per_step": ms, "value": 1e3 / ms, "unit": "pairs/s", "steps": 10, "warmup": 3,
+                "workload": f"{arch}: single 960x540 pair (padded to 576), eval forward",
+                "head_kernel": {"entry": entry, "what": label, "avg_launch_ms": head_ms, "launches_timed": len(ev),
+                                "bound": "fp32 VALU (exp + FMA per logit)", "logits_per_launch": nlog,
+                                "achieved_Glogits_per_s": nlog / head_ms / 1e6,
+                                "not_materialised_bytes": 3 * 4.0 * H * W * D}}
+            note(f"{arch}: eval forward {ms:.2f} ms/pair, head kernel {head_ms:.3f} ms")
+            del m2, lv, rv
         # cfg 5: cost-volume microbench, 1920x1080 D=256 -> L,R [1,32,270,480], D'=64, 2.16 GB per build
         f5l, f5r = (torch.randn(1, 32, 270, 480, device=dev) for _ in range(2))
         for _ in range(5):

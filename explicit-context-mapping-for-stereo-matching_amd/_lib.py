@@ -31,8 +31,10 @@ PROTOTYPES = {
     "ecm_context_weights_bwd": (_I, [_P] * 11 + [_P, _LL, _I, _I, _I, _I, _I, _P]),
     "ecm_volume_mapping_fwd": (_I, [_P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_trilinear_softargmin_fwd": (_I, [_P, _LL, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "ecm_volume_mapping_bwd": (_I, [_P, _LL, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "ecm_trilinear_softargmin_bwd": (_I, [_P, _LL, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ecm_volume_mapping_bwd_scratch_bytes": (_LL, [_I] * 6),
+    "ecm_volume_mapping_bwd": (_I, [_P, _LL, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _P]),
+    "ecm_trilinear_softargmin_bwd_scratch_bytes": (_LL, [_I] * 7),
+    "ecm_trilinear_softargmin_bwd": (_I, [_P, _LL, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_weights9_bwd_scratch_bytes": (_LL, [_I, _I, _I, _I]),
     "ecm_weights9_bwd": (_I, [_P] * 11 + [_P, _LL, _I, _I, _I, _I, _P]),
     "ecm_conv3d_packed_floats": (_LL, [_I, _I]),

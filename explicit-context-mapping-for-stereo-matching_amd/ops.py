@@ -343,8 +343,10 @@ class VolumeMapping(torch.autograd.Function):
         NH, B, Dl, h, w = c.shape
         g = _c(g)
         gc, gm5, gmt3 = _empty_like(c), _empty_like(m5), _empty_like(mt3)
+        nb = _lib.query("ecm_volume_mapping_bwd_scratch_bytes", NH, B, Dl, h, w, ctx.scale)
+        scratch = _scratch(nb, c.device)
         _lib.call("ecm_volume_mapping_bwd", _p(c), C.c_longlong(B * Dl * h * w), _p(m5), _p(mt3), _p(g), _p(gc), _p(gm5),
-                  _p(gmt3), NH, B, Dl, h, w, ctx.scale, _stream())
+                  _p(gmt3), _p(scratch), C.c_longlong(nb), NH, B, Dl, h, w, ctx.scale, _stream())
         return gc, gm5, gmt3, None
 
 
@@ -374,8 +376,10 @@ class TrilinearSoftArgmin(torch.autograd.Function):
         Do, H, W = ctx.dims
         g = _c(g)
         gc = _empty_like(c)
-        _lib.call("ecm_trilinear_softargmin_bwd", _p(c), C.c_longlong(B * Dl * h * w), _p(g), _p(gc), NH, B, Dl, h, w, Do, H,
-                  W, _stream())
+        nb = _lib.query("ecm_trilinear_softargmin_bwd_scratch_bytes", NH, B, Dl, h, w, H, W)
+        scratch = _scratch(nb, c.device)
+        _lib.call("ecm_trilinear_softargmin_bwd", _p(c), C.c_longlong(B * Dl * h * w), _p(g), _p(gc), _p(scratch),
+                  C.c_longlong(nb), NH, B, Dl, h, w, Do, H, W, _stream())
         return gc, None, None, None
 
 

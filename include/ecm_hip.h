@@ -99,16 +99,22 @@ int ecm_context_weights_bwd(const float* lr, const float* hr, const float* W0, c
  * c: raw classifier outputs [nheads][B,Dl,h,w] (head k uses c_0+...+c_k); disp: [nheads,B,H,W]. */
 int ecm_volume_mapping_fwd(const float* c0, long long head_stride, const float* m5, const float* mt3, float* disp,
                            int nheads, int B, int Dl, int h, int w, int s, void* stream);
-/* Gradients of c (same packing), m5 and mt3 from gdisp [nheads,B,H,W]; s must be a power of two.  gc0 and gmt3 are
- * zeroed by the call (hipMemsetAsync on the stream) and accumulated with float atomics. */
+/* Gradients of c (same packing), m5 and mt3 from gdisp [nheads,B,H,W]; s must be a power of two <= 64.  Deterministic:
+ * every sum is taken in a fixed order (per-row partial sums in `scratch`, gathered by a second kernel; no float atomics),
+ * every output element is written exactly once. */
+long long ecm_volume_mapping_bwd_scratch_bytes(int nheads, int B, int Dl, int h, int w, int s);
 int ecm_volume_mapping_bwd(const float* c0, long long head_stride, const float* m5, const float* mt3, const float* gdisp,
-                           float* gc0, float* gm5, float* gmt3, int nheads, int B, int Dl, int h, int w, int s, void* stream);
+                           float* gc0, float* gm5, float* gmt3, void* scratch, long long scratch_bytes,
+                           int nheads, int B, int Dl, int h, int w, int s, void* stream);
 
 /* ---- a11: trilinear head (bilinear_cmf.py:447-471), fused: F.interpolate(trilinear, align_corners=False) of the LR
  * logits to [Do,H,W], softmax over Do, regression.  c as above (cumulative over heads); disp: [nheads,B,H,W]. */
 int ecm_trilinear_softargmin_fwd(const float* c0, long long head_stride, float* disp,
                                  int nheads, int B, int Dl, int h, int w, int Do, int H, int W, void* stream);
+/* Deterministic (per-pixel plane gradients in `scratch`, then separable fixed-order reductions along x and y). */
+long long ecm_trilinear_softargmin_bwd_scratch_bytes(int nheads, int B, int Dl, int h, int w, int H, int W);
 int ecm_trilinear_softargmin_bwd(const float* c0, long long head_stride, const float* gdisp, float* gc0,
+                                 void* scratch, long long scratch_bytes,
                                  int nheads, int B, int Dl, int h, int w, int Do, int H, int W, void* stream);
 
 /* ---- a5-a7: 3-D aggregation (cmfsm.py:49-58 convbn_3d, 240-303 hourglass, 604-634) ----------

@@ -34,22 +34,29 @@ __device__ __forceinline__ void gn_affine(float mean, float rstd, float gamma, f
     sh = __builtin_fmaf(-mean, a, beta);
 }
 
-// stage 1: partial (sum, sumsq) of chunk `blockIdx.x` of span `blockIdx.y` (= b*32+g); span = n contiguous floats
+// Statistics are accumulated as sums of d = x - K and d^2 around a PIVOT K = the span's first element, and the variance is
+// E[d^2] - E[d]^2: the textbook E[x^2] - E[x]^2 cancels catastrophically when |mean| >> std -- the SPP branches normalise
+// maps of 2..6 pixels per group whose values differ in the third digit, and round 2's kernels lost three digits of the
+// normalised value there (measured: 1.2e-3 relative against 1.9e-5 for torch's Welford form, which put the whole
+// encoder's low-resolution feature 12x further from the fp64 truth than the reference's fp32).
+// stage 1: partial (sum d, sum d^2) of chunk `blockIdx.x` of span `blockIdx.y` (= b*32+g); span = n contiguous floats
 __global__ __launch_bounds__(THREADS) void gn_stats_partial(const float* __restrict__ x, float* __restrict__ part,
                                                             long long n, int nchunks) {
     __shared__ float sm[2 * THREADS / 64];
     const float* p = x + (size_t)blockIdx.y * n;
+    const float K = p[0];
     const long long beg = (long long)blockIdx.x * CHUNK;
     const long long end = beg + CHUNK < n ? beg + CHUNK : n;
     float s = 0.f, q = 0.f;
     if ((n & 3) == 0) {
         for (long long i = beg + threadIdx.x * 4; i < end; i += THREADS * 4) {
-            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            float4 v = *reinterpret_cast<const float4*>(p + i);
+            v.x -= K; v.y -= K; v.z -= K; v.w -= K;
             s += (v.x + v.y) + (v.z + v.w);
             q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
     } else {
-        for (long long i = beg + threadIdx.x; i < end; i += THREADS) { const float v = p[i]; s += v; q += v * v; }
+        for (long long i = beg + threadIdx.x; i < end; i += THREADS) { const float v = p[i] - K; s += v; q += v * v; }
     }
     block_reduce2(s, q, sm);
     if (threadIdx.x == 0) {
@@ -59,14 +66,15 @@ __global__ __launch_bounds__(THREADS) void gn_stats_partial(const float* __restr
 }
 
 // stage 2: one thread per span, fixed-order sum in double -> (mean, rstd)
-__global__ void gn_stats_final(const float* __restrict__ part, float* __restrict__ mean_rstd, int nspans, int nchunks,
-                               long long n, float eps) {
+__global__ void gn_stats_final(const float* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean_rstd,
+                               int nspans, int nchunks, long long n, float eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nspans) return;
     double s = 0.0, q = 0.0;
     for (int c = 0; c < nchunks; ++c) { s += part[((size_t)i * nchunks + c) * 2]; q += part[((size_t)i * nchunks + c) * 2 + 1]; }
-    const double mean = s / (double)n;
-    double var = q / (double)n - mean * mean;
+    const double dm = s / (double)n;                    // mean of x - K
+    const double mean = (double)x[(size_t)i * n] + dm;
+    double var = q / (double)n - dm * dm;
     if (var < 0.0) var = 0.0;
     mean_rstd[2 * i] = (float)mean;
     mean_rstd[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -415,13 +423,19 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         const int c = g * cpg + cig;
         const size_t base = ((size_t)b * C + c) * S;
         const auto xr = slice_rsrc(x + base + (size_t)v0 * 4, v1 - v0);
+        // pivot of the span (see gn_stats_partial): its first element, the same for every member of the cluster
+        const float K = x[((size_t)b * C + (size_t)g * cpg) * S];
+        const unsigned nslice = (unsigned)(v1 - v0), vidx = (unsigned)(wave * MAXV4 * 64 + lane);
         float4 v[MAXV4];
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXV4; ++j) {
             v[j] = slice_ld(xr, toff + j * 1024);
-            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-            q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+            const bool in = vidx + (unsigned)j * 64u < nslice;          // float4s past the slice read as 0: no part of the sums
+            const float dx = in ? v[j].x - K : 0.f, dy = in ? v[j].y - K : 0.f;
+            const float dz = in ? v[j].z - K : 0.f, dw = in ? v[j].w - K : 0.f;
+            s += (dx + dy) + (dz + dw);
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
         }
         block_reduce2(s, q, sm);
         unsigned long long* sp = ctl.slots + (size_t)span * cl;
@@ -442,10 +456,10 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         ds = (smd[0] + smd[2]) + (smd[4] + smd[6]);
         dq = (smd[1] + smd[3]) + (smd[5] + smd[7]);
         const double n = (double)cpg * (double)S;
-        const double dmean = ds / n;
-        double var = dq / n - dmean * dmean;
+        const double dm = ds / n;                       // mean of x - K
+        double var = dq / n - dm * dm;
         if (var < 0.0) var = 0.0;
-        float mean = (float)dmean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        float mean = (float)((double)K + dm), rstd = (float)(1.0 / sqrt(var + (double)eps));
         if (!arrived) {
             mean = rstd = __builtin_nanf("");
             if (tid == 0) report_timeout(ctl.status);
@@ -609,7 +623,7 @@ extern "C" int ecm_gn3d_stats(const float* x, float* mean_rstd, void* scratch, l
     float* part = static_cast<float*>(scratch);
     hipLaunchKernelGGL(gn_stats_partial, dim3(nchunks, B * GROUPS), dim3(THREADS), 0, ecm_stream(stream), x, part, n,
                        nchunks);
-    hipLaunchKernelGGL(gn_stats_final, dim3((B * GROUPS + 63) / 64), dim3(64), 0, ecm_stream(stream), part, mean_rstd,
+    hipLaunchKernelGGL(gn_stats_final, dim3((B * GROUPS + 63) / 64), dim3(64), 0, ecm_stream(stream), x, part, mean_rstd,
                        B * GROUPS, nchunks, n, eps);
     return ECM_LAUNCH_RESULT();
 }

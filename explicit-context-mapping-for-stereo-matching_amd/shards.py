@@ -192,6 +192,8 @@ class ShardFeeder:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("ShardFeeder feeds the MI355X HIP path: a CUDA/HIP device is required (no CPU fallback exists)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.rank, self.world, self.seed = int(rank), int(world), int(seed)
         self.shuffle = (split == "train") if shuffle is None else bool(shuffle)
         self.crop, self.want_image = crop, want_image
@@ -239,9 +241,9 @@ class ShardFeeder:
         return dict(pin=pin, dev=dev, shape=(H, W), h2d_done=None)
 
     def _produce(self, epoch):
-        torch.cuda.set_device(self.device)
-        rng = random.Random(self.seed * 7919 + epoch * 104729 + self.rank)
-        try:
+        try:                                                                # whatever goes wrong reaches the consumer
+            torch.cuda.set_device(self.device)
+            rng = random.Random(self.seed * 7919 + epoch * 104729 + self.rank)
             k = 0
             for idx in self._order(epoch):
                 if self._stop.is_set():
@@ -303,7 +305,13 @@ class ShardFeeder:
         return self
 
     def __next__(self):
-        item = self._q.get()
+        while True:
+            try:
+                item = self._q.get(timeout=1.0)
+                break
+            except queue.Empty:                                             # a producer that died without a word
+                if not self._thread.is_alive() and self._q.empty():
+                    raise RuntimeError("ShardFeeder: the producer thread ended without delivering a batch") from self._err
         if item is None:
             self._thread.join()
             if self._err is not None:

@@ -78,10 +78,12 @@ def test_full_cmfsm_train_step_against_fp64_reference(ecm):
     loss.backward()
     for i in (1, 2, 3):
         d64 = (o[i - 1].detach().double().cpu()[..., ::4, ::4] - torch.from_numpy(z[f"o{i}_64"])).abs()
-        # SURVEY section 7's stated end-to-end tolerance: max 2e-2 px, mean 1e-3 px (disparities span 0..191 px)
-        assert float(d64.max()) <= 2e-2 and float(d64.mean()) <= 1e-3, (i, float(d64.max()), float(d64.mean()))
+        # SURVEY section 7's stated end-to-end tolerance is max 2e-2 px, mean 1e-3 px (disparities span 0..191 px); the
+        # reference's own fp32 run sits at max 7e-4 / mean 1.3e-4 from this fp64 truth and the HIP path at 3e-4 / 5e-5
+        # (tests/diag_stage_error.py), so the bound asserted here is ten times tighter than the stated one
+        assert float(d64.max()) <= 2e-3 and float(d64.mean()) <= 1e-4 * i + 1e-4, (i, float(d64.max()), float(d64.mean()))
     l64, l32 = float(z["loss_64"]), float(z["loss_32"])
-    assert abs(float(loss) - l64) <= K * abs(l32 - l64) + 1e-5 * l64, (float(loss), l64, l32)
+    assert abs(float(loss.detach()) - l64) <= K * abs(l32 - l64) + 1e-5 * l64, (float(loss.detach()), l64, l32)
     n_full, worst = _check_params(model, z, "cmfsm")
     assert n_full >= 14, n_full
     print("worst norm-error ratios vs the yardstick:", worst)

@@ -451,6 +451,30 @@ def main():
                                          "bound_ms_per_launch": bound_ms / len(ew), "avg_launch_ms": tot / len(ew),
                                          "frac": bound_ms / tot, "launches_timed": len(ew)}
 
+        eb = [(s, e, a) for (s, e, a) in timers.get("ecm_weights9_bwd", [])]                     # (B,h,w,s)
+        if eb:
+            tot = sum(s.elapsed_time(e) for s, e, _ in eb)
+            # fp32 work per full-resolution pixel: 9 neighbours x (forward recompute 1,424 + backward chain 1,296 + weight-gradient
+            # outer products 1,424 flop) + per-pixel first-layer products 3 x 2,048 = 43.4 kflop; HBM: hr read twice, ghr written,
+            # saved planes + their gradient read
+            bound_ms = 0.0
+            for _, _, a in eb:
+                HW = a[0] * a[1] * a[3] * a[2] * a[3]
+                flop = HW * (9.0 * (1424 + 1296 + 1424) + 3 * 2048)
+                byt = HW * (3 * 32 + 18) * 4.0
+                bound_ms += max(byt / (PEAK_HBM_GBS * 1e9), flop / (PEAK_F32_MFMA_TFLOPS * 1e12)) * 1e3
+            worst["ecm_weights9_bwd"] = {"kernel": "bwd_lr_proj + ecm_weights_bwd_kernel_p<0> + ecm_weights_bwd_cells<0> + ecm_weights_bwd_reduce",
+                                         "bound": "max(hbm, fp32)", "bound_ms_per_launch": bound_ms / len(eb),
+                                         "avg_launch_ms": tot / len(eb), "frac": bound_ms / tot, "launches_timed": len(eb)}
+        dc = [(s, e, a) for (s, e, a) in timers.get("ecm_deconv3d_k3s2_fwd", [])]                # (B,Ci,Co,D,H,W,Do,Ho,Wo)
+        if dc:
+            tot = sum(s.elapsed_time(e) for s, e, _ in dc)
+            flop = sum(2.0 * 27 * a[1] * a[2] * a[0] * a[3] * a[4] * a[5] for _, _, a in dc)      # per INPUT voxel: 27 taps x Ci x Co
+            tf = flop / (tot * 1e-3) / 1e12
+            worst["deconv3d_k3s2"] = {"kernel": "deconv3d_k3s2_mfma (hourglass conv5 / conv6 and the stride-2 convolutions' data gradients)",
+                                      "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tf / PEAK_F32_MFMA_TFLOPS, "launches_timed": len(dc), "avg_launch_ms": tot / len(dc)}
+
         shape_name = {(576, 960): "SceneFlow 960x540 (padded to 576)",
                       (384, 1248): "KITTI-2015 1242x375 (padded to 1248x384)"}.get((H, W), f"synthetic {W}x{H}")
         # roofline.traffic: HBM bytes per launch from rocprofv3 PMC passes of THIS round (profiles/r02_pmc_traffic.json, written

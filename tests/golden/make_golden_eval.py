@@ -69,3 +69,23 @@ np.savez_compressed(path, epe=epe, u16_head=u16[:8], u16_sub=u16[::5, ::5],
                     pad_rgb_rowsum=pad[..., :6].sum(axis=(1, 2), dtype=np.float64),
                     pad_rgb_colsum=pad[..., :6].sum(axis=(0, 2), dtype=np.float64))
 print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)", epe)
+
+# (4) train_kitti.py:186, 196-216 -- the KITTI fine-tuning step's loss and its validation metrics (EPE, 3-px / 5 % error)
+# on the inputs tests regenerate from `oracle.weights.seeded` (fixture g10): mask, squeeze, loss, epe, error_map, loss_3
+from oracle.weights import seeded  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+Bk, Hk, Wk = 2, 37, 53
+gtk = seeded("g10.gt", Bk, Hk, Wk).abs() * 120.0
+gtk[:, ::7, ::5] = 0.0
+outs = [(gtk + seeded(f"g10.p{i}", Bk, Hk, Wk) * s).unsqueeze(1) for i, s in ((1, 4.0), (2, 2.0), (3, 3.0))]
+nsm = dict(torch=torch, F=F, disparity=gtk, ones=torch.ones(1), zeros=torch.zeros(1))
+run_reference_lines("/root/reference/train_kitti.py", 186, 186, nsm)                       # mask
+nsm.update(output1=outs[0], output2=outs[1], output3=outs[2])
+run_reference_lines("/root/reference/train_kitti.py", 196, 198, nsm)                       # squeeze x3
+run_reference_lines("/root/reference/train_kitti.py", 205, 207, nsm)                       # loss
+run_reference_lines("/root/reference/train_kitti.py", 212, 216, nsm)                       # squeeze (no-op), epe, error_map, loss_3
+path = os.path.join(OUT, "g10_kitti_metrics.npz")
+np.savez_compressed(path, loss=nsm["loss"].numpy(), epe=nsm["epe"].numpy(), loss_3=nsm["loss_3"].numpy(),
+                    n_mask=np.array(int(nsm["mask"].sum())))
+print(f"wrote {path}", float(nsm["loss"]), float(nsm["epe"]), float(nsm["loss_3"]))

@@ -145,3 +145,20 @@ def test_eval_step_reproduces_test_py(ecm):
     want = O.sceneflow_eval_epe(o3.cpu(), gt.cpu())
     np.testing.assert_allclose(out[:3].numpy(), np.array(want), rtol=1e-5)
     ecm.ops.check_async_errors()
+
+
+def test_stereo_loss_and_kitti_metrics_vs_reference_statements(ecm):
+    """ops.stereo_loss3 (loss.hip) against the reference's own loss / EPE / 3-px statements (train_kitti.py:186, 196-216,
+    executed in the build container: fixture g10)."""
+    from conftest import load_golden
+    from oracle.weights import seeded
+    g = load_golden("g10_kitti_metrics")
+    B, H, W = 2, 37, 53
+    gt = seeded("g10.gt", B, H, W).abs() * 120.0
+    gt[:, ::7, ::5] = 0.0
+    outs = [(gt + seeded(f"g10.p{i}", B, H, W) * s).unsqueeze(1).cuda() for i, s in ((1, 4.0), (2, 2.0), (3, 3.0))]
+    loss, met = ecm.ops.stereo_loss3(outs, gt.cuda())
+    torch.testing.assert_close(loss.cpu(), g["loss"], rtol=1e-5, atol=1e-6)
+    assert float(met[1]) == float(g["n_mask"])
+    torch.testing.assert_close(met[2].cpu(), g["epe"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(met[3].cpu(), g["loss_3"], rtol=1e-5, atol=1e-4)

@@ -273,7 +273,7 @@ def test_train_step_b4_collapsed_vs_explicit(ecm, B, H, W):
             loss = dist.masked_smooth_l1_x3(model(left, right), gt, 192)
             loss.backward()
             torch.cuda.synchronize()
-            res[tag] = (float(loss), {k: p.grad.clone() for k, p in model.named_parameters()})
+            res[tag] = (float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters()})
             model.zero_grad(set_to_none=True)
     finally:
         mdl.EXPLICIT_COST_VOLUME = prev

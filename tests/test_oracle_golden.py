@@ -230,3 +230,19 @@ def test_g9_eval_harness_restatements():
     assert np.array_equal(pad[::7, ::11, :6].astype(np.uint8), g["pad_rgb_sub"])
     assert np.array_equal(pad[..., :6].sum(axis=(1, 2), dtype=np.float64), g["pad_rgb_rowsum"])
     assert np.array_equal(pad[..., :6].sum(axis=(0, 2), dtype=np.float64), g["pad_rgb_colsum"])
+
+
+def test_kitti_loss_and_metrics_golden():
+    """O.train_loss / O.kitti_metrics against the reference's own statements (train_kitti.py:186, 196-216) executed in the
+    build container (fixture g10, tests/golden/make_golden_eval.py): the loss, the end-point error and the 3-px / 5 % rate."""
+    g = load_golden("g10_kitti_metrics")
+    B, H, W = 2, 37, 53
+    gt = seeded("g10.gt", B, H, W).abs() * 120.0
+    gt[:, ::7, ::5] = 0.0
+    outs = [(gt + seeded(f"g10.p{i}", B, H, W) * s).unsqueeze(1) for i, s in ((1, 4.0), (2, 2.0), (3, 3.0))]
+    assert int(((gt < 192) & (gt > 0)).sum()) == int(g["n_mask"])
+    torch.testing.assert_close(O.train_loss(outs, gt), g["loss"], rtol=0, atol=0)
+    epe, err3 = O.kitti_metrics(outs[2], gt)
+    torch.testing.assert_close(epe, g["epe"], rtol=0, atol=0)
+    torch.testing.assert_close(err3, g["loss_3"], rtol=0, atol=0)
+    assert 5.0 < float(err3) < 60.0                                  # the fixture exercises both branches of the 3-px test

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wino|wgrad|wino_wgrad|gn|costvol] [B]"""
+"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wino|wgrad|wino_wgrad|gn|ecmw_bwd|costvol] [B]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,6 +30,14 @@ elif which == "gn":
     for _ in range(3):
         y = ops.group_norm_act(x, gm, bt, None, True)
         torch.autograd.grad(y, x, G)
+elif which == "ecmw_bwd":
+    h, w = 144, 240
+    lr, hr = torch.randn(B, 32, h, w, device=dev), torch.randn(B, 32, 4 * h, 4 * w, device=dev)
+    Ws = [torch.randn(*s, device=dev) * 0.2 for s in ((32, 66, 1, 1), (16, 32, 1, 1), (8, 16, 1, 1), (1, 8, 1, 1))]
+    a = [t.clone().requires_grad_() for t in (lr, hr, *Ws)]
+    w9 = ops.ecm_weights9(*a)
+    g9 = torch.randn_like(w9)
+    for _ in range(5): torch.autograd.grad(w9, a, g9, retain_graph=True)
 elif which == "costvol":
     L, R = torch.randn(B, 32, 144, 240, device=dev), torch.randn(B, 32, 144, 240, device=dev)
     for _ in range(5): c = ops.cost_volume(L, R, 48)

@@ -72,6 +72,10 @@ def main():
              2 * 4 * 32 * 48 * 144 * 240 * 4),
             ("conv3d_wgrad_wino_32to32_B4", "conv3d_wgrad_mfma", ("ww_fetch", "ww_write"), fac.get("read_b32_rows", 1.0),
              2 * 4 * 32 * 48 * 144 * 240 * 4),
+            # ECM weights backward (round 3): hr read twice + saved planes + their gradient (4-byte-per-lane global loads, rows of
+            # 16 consecutive floats), ghr + gA9 written
+            ("ecm_weights_bwd_kernel_p_B4", "ecm_weights_bwd_kernel_p", ("ew_fetch", "ew_write"), fac.get("read_b32_buffer", 2.0),
+             4 * (3 * 32 + 18) * 576 * 960 * 4),
             ("costvol_fwd_v4_B4", "costvol_fwd", ("cv_fetch", "cv_write"), fac.get("read_b128_global", 2.0),
              4 * (2 * 32 * 48 * 144 * 240 + 2 * 32 * 144 * 240) * 4)):
         f = mean_kib(counters(f"{root}/{dirs[0]}"), sub, "FETCH_SIZE", 1)
@@ -82,7 +86,7 @@ def main():
         out[key] = {"FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w, "read_bytes_calibrated": rd, "write_bytes_calibrated": wr,
                     "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes": alg, "ratio_to_algorithmic": (rd + wr) / alg}
     out["note"] = ("rocprofv3 PMC (FETCH_SIZE / WRITE_SIZE in separate passes), B=4, calibrated with tools/micro/fetch_calib "
-                   "(profiles/r02_pmc_traffic.json)")
+                   "(tools/pmc_traffic.py)")
     json.dump(out, sys.stdout, indent=1)
     print()
 

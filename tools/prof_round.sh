@@ -1,0 +1,28 @@
+# Profiling battery of a round (run on the MI355X box through gpurun): rocprofv3 kernel stats of bench.py, calibrated FETCH/WRITE
+# traffic and matrix-pipe utilisation passes (separate --pmc runs), summarised into gpurun_out/prof_r3/.
+set -e
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+O=$R/gpurun_out/prof_r3
+rm -rf $O; mkdir -p $O
+echo stats; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+P="rocprofv3 --kernel-trace --output-format csv"
+echo calib; $P --pmc FETCH_SIZE -d $O/calib_fetch -- $R/tools/micro/fetch_calib > /dev/null 2>&1
+$P --pmc WRITE_SIZE -d $O/calib_write -- $R/tools/micro/fetch_calib > /dev/null 2>&1
+for w in wino:wino wino_wgrad:ww costvol:cv ecmw_bwd:ew conv:conv; do
+  k=${w%%:*}; t=${w##*:}
+  echo $k; $P --pmc FETCH_SIZE -d $O/${t}_fetch -- python3 $R/tools/conv_only.py $k 4 > /dev/null 2>&1
+  $P --pmc WRITE_SIZE -d $O/${t}_write -- python3 $R/tools/conv_only.py $k 4 > /dev/null 2>&1
+done
+M="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+for k in wino wino_wgrad ecmw_bwd; do
+  echo mfma $k; $P --pmc $M -d $O/mfma_$k -- python3 $R/tools/conv_only.py $k 4 > /dev/null 2>&1
+done
+cd $R
+python3 tools/pmc_traffic.py $O > $O/pmc_traffic.json
+python3 tools/pmc_mfma_summary.py wino=$O/mfma_wino wino_wgrad=$O/mfma_wino_wgrad ecmw_bwd=$O/mfma_ecmw_bwd > $O/pmc_mfma_util.json
+cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+# keep the merged output small: drop the raw traces
+find $O -name "*kernel_trace.csv" -size +2M -delete
+find $O -name "*.db" -delete
+du -sh $O

@@ -81,6 +81,10 @@ PROTOTYPES = {
     "ecm_gn3d_apply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _LL, _I, _P]),
     "ecm_gn3d_fwd": (_I, [_P] * 7 + [_LL, _I, _I, _LL, _I, _F, _P]),
     "ecm_gn3d_bwd": (_I, [_P] * 11 + [_LL, _I, _I, _LL, _I, _P]),
+    "ecm_gn3d_cluster_bytes": (_LL, [_I]),
+    "ecm_gn3d_cluster_preset": (_I, [_P, _LL, _P]),
+    "ecm_gn3d_fwd_p": (_I, [_P] * 7 + [_LL, _P, _LL, _I, _I, _LL, _I, _F, _P]),
+    "ecm_gn3d_bwd_p": (_I, [_P] * 11 + [_LL, _P, _LL, _I, _I, _LL, _I, _P]),
 }
 
 _lib = None

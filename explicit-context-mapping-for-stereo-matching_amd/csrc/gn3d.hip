@@ -391,10 +391,28 @@ inline int resident_workgroups(K kern) {
 struct FusedCtl {
     unsigned long long* slots;
     unsigned* ticket;
+    unsigned* done;                   // per span: members that have collected (preset 0xFFFFFFFF); the last one restores the
+                                      // span's slots and this counter to their preset state (see ecm_gn3d_fwd_p)
     unsigned* status;                 // host-mapped sticky error word
     unsigned long long poll_ticks;    // 100 MHz ticks
     int dynamic;                      // 1: tickets, 0: static ids (diagnostic)
 };
+
+// Self-cleaning exchange memory.  Every member of a cluster, once it has COLLECTED the span's slots, counts itself on the
+// span's `done` word; the last one (nobody polls those slots any more) puts the slots and the word back to their preset
+// (all-ones) state, and the workgroup that draws the very last ticket of the launch does the same for the ticket counter.
+// A launch that ends without a time-out therefore leaves the exchange memory exactly as it found it, and a caller that
+// keeps it across calls (ecm_gn3d_fwd_p / _bwd_p) needs no memset per launch (172 per training step before).
+__device__ __forceinline__ bool cluster_done(const FusedCtl& ctl, const Tickets& tk, int span, int cl, unsigned tnext) {
+    if (tk.dynamic && tnext == tk.total + tk.stride - 1u)            // the last draw of the launch (stride == gridDim.x)
+        __hip_atomic_store(ctl.ticket, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = atomicAdd(ctl.done + span, 1u);              // preset 0xFFFFFFFF: the k-th arrival reads k - 2
+    return old + 2u == (unsigned)cl;
+}
+__device__ __forceinline__ void cluster_restore(const FusedCtl& ctl, unsigned long long* sp, int span, int cl, int tid) {
+    if (tid < cl) __hip_atomic_store(sp + tid, SLOT_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(ctl.done + span, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <bool RELU, bool SKIP>
 __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
     constexpr int MAXV4 = FWD_MAXV4;
     __shared__ float sm[2 * THREADS / 64];
     __shared__ double smd[2 * THREADS / 64];
-    __shared__ unsigned tick_s;
+    __shared__ unsigned tick_s, last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = cpg * wpc;
     const long long nv4 = S >> 2;                       // < 2^31 (checked by the host): 32-bit indices within a channel
@@ -449,10 +467,14 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         // (the drawn ticket could belong to the very cluster it waits on).  From here on nothing blocks, and the draw's
         // latency hides under the finishing pass.
         unsigned tnext = 0;
-        if (tid == 0) tnext = tk.next(t);
+        if (tid == 0) {
+            tnext = tk.next(t);
+            last_s = cluster_done(ctl, tk, span, cl, tnext) ? 1u : 0u;
+        }
         ds = wave_sum_d(ds); dq = wave_sum_d(dq);
         if (lane == 0) { smd[wave * 2] = ds; smd[wave * 2 + 1] = dq; }
         __syncthreads();
+        if (last_s) cluster_restore(ctl, sp, span, cl, tid);
         ds = (smd[0] + smd[2]) + (smd[4] + smd[6]);
         dq = (smd[1] + smd[3]) + (smd[5] + smd[7]);
         const double n = (double)cpg * (double)S;
@@ -498,7 +520,7 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
     constexpr int MAXV4 = BWD_MAXV4;
     __shared__ float sm[2 * THREADS / 64];
     __shared__ double chs[2 * FUSED_MAX_CPG];
-    __shared__ unsigned tick_s;
+    __shared__ unsigned tick_s, last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = cpg * wpc;
     const long long nv4 = S >> 2;                       // < 2^31 (checked by the host): 32-bit indices within a channel
@@ -566,7 +588,10 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
         }
         const bool arrived = __syncthreads_and(got) != 0;
         unsigned tnext = 0;
-        if (tid == 0) tnext = tk.next(t);             // only after the wait (see gn_fused_fwd)
+        if (tid == 0) {
+            tnext = tk.next(t);                        // only after the wait (see gn_fused_fwd)
+            last_s = cluster_done(ctl, tk, span, cl, tnext) ? 1u : 0u;
+        }
         if (!arrived && tid == 0) report_timeout(ctl.status);
         float s1 = 0.f, s2 = 0.f;
         for (int j = 0; j < cpg; ++j) {
@@ -593,11 +618,12 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
         if (tid == 0) tick_s = tnext;
         __syncthreads();          // tick_s; chs / sm are reused by the next span
         t = tick_s;
+        if (last_s) cluster_restore(ctl, sp, span, cl, tid);
     }
 }
 
-// 64-bit slots [B*32][cl <= FUSED_MAX_CL_RUN] + one 16-byte line for the ticket counter, in floats
-inline long long fused_scratch_floats(int B) { return (long long)B * GROUPS * FUSED_MAX_CL_RUN * 2 + 4; }
+// 64-bit slots [B*32][cl <= FUSED_MAX_CL_RUN] + one 16-byte line for the ticket counter + one `done` word per span, in floats
+inline long long fused_scratch_floats(int B) { return (long long)B * GROUPS * FUSED_MAX_CL_RUN * 2 + 4 + (long long)B * GROUPS; }
 
 inline int chunks_of(long long n) { return (int)((n + CHUNK - 1) / CHUNK); }
 
@@ -682,7 +708,7 @@ int gn_ctl_init_locked(GnControl& c) {
 // Launch helpers of the fused kernels; -100 = the shape (or the mode) needs the two-stage path.
 struct FusedLaunch { FusedGeom g; FusedCtl ctl; int rc; };
 
-inline FusedLaunch fused_prepare(float* scratch, int B, int C, long long S, int maxv4, int resident, hipStream_t st) {
+inline FusedLaunch fused_prepare(float* scratch, bool preset, int B, int C, long long S, int maxv4, int resident, hipStream_t st) {
     FusedLaunch L{};
     GnControl& c = gn_ctl();
     int mode;
@@ -705,19 +731,24 @@ inline FusedLaunch fused_prepare(float* scratch, int B, int C, long long S, int 
     L.ctl.slots = reinterpret_cast<unsigned long long*>(scratch);
     const size_t nslots = (size_t)L.g.nspans * L.g.cl;
     L.ctl.ticket = reinterpret_cast<unsigned*>(L.ctl.slots + nslots);
-    // one memset presets the slots to EMPTY and the ticket counter to 0xFFFFFFFF (first draw wraps to ticket 0)
-    const hipError_t e = hipMemsetAsync(L.ctl.slots, 0xff, nslots * sizeof(unsigned long long) + 16, st);
-    L.rc = e == hipSuccess ? 0 : (int)e;
+    L.ctl.done = L.ctl.ticket + 4;
+    L.rc = 0;
+    if (!preset) {
+        // one memset presets the slots to EMPTY, the ticket counter to 0xFFFFFFFF (first draw wraps to ticket 0) and the
+        // spans' `done` words; exchange memory kept by the caller (ecm_gn3d_*_p) is in that state already
+        const hipError_t e = hipMemsetAsync(L.ctl.slots, 0xff, nslots * sizeof(unsigned long long) + 16 + (size_t)L.g.nspans * 4, st);
+        L.rc = e == hipSuccess ? 0 : (int)e;
+    }
     return L;
 }
 
 template <bool RELU, bool SKIP>
 int launch_fused_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, float* mean_rstd,
-                     float* scratch, int B, int C, long long S, float eps, hipStream_t st) {
+                     float* scratch, bool preset, int B, int C, long long S, float eps, hipStream_t st) {
     auto kern = gn_fused_fwd<RELU, SKIP>;
     static int resident = -1;
     if (resident < 0) resident = resident_workgroups(kern);
-    const FusedLaunch L = fused_prepare(scratch, B, C, S, FWD_MAXV4, resident, st);
+    const FusedLaunch L = fused_prepare(scratch, preset, B, C, S, FWD_MAXV4, resident, st);
     if (L.rc) return L.rc;
     hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), 0, st, x, gamma, beta, skip, y, mean_rstd, L.ctl, C,
                        S, L.g.cpg, L.g.wpc, L.g.nspans, L.g.v4_per_wg, eps);
@@ -726,12 +757,12 @@ int launch_fused_fwd(const float* x, const float* gamma, const float* beta, cons
 
 template <int MASK, int GSKIP>
 int launch_fused_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
-                     const float* gy, float* gx, float* gskip, float* chan, float* scratch, int B, int C, long long S,
+                     const float* gy, float* gx, float* gskip, float* chan, float* scratch, bool preset, int B, int C, long long S,
                      hipStream_t st) {
     auto kern = gn_fused_bwd<MASK, GSKIP>;
     static int resident = -1;
     if (resident < 0) resident = resident_workgroups(kern);
-    const FusedLaunch L = fused_prepare(scratch, B, C, S, BWD_MAXV4, resident, st);
+    const FusedLaunch L = fused_prepare(scratch, preset, B, C, S, BWD_MAXV4, resident, st);
     if (L.rc) return L.rc;
     hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), 0, st, x, mean_rstd, gamma, beta, y, gy, gx, gskip,
                        chan, L.ctl, C, S, L.g.cpg, L.g.wpc, L.g.nspans, L.g.v4_per_wg);
@@ -774,46 +805,46 @@ extern "C" int ecm_async_status(int clear) {
     return v ? ECM_EASYNC : 0;
 }
 
-extern "C" int ecm_gn3d_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y,
-                            float* mean_rstd, void* scratch, long long scratch_bytes, int B, int C, long long S,
-                            int relu, float eps, void* stream) {
-    ECM_CHECK_ARG(x && gamma && beta && y && mean_rstd && scratch && B > 0 && C > 0 && S > 0);
+namespace {
+// cluster: the exchange memory of the one-pass kernels (slots, ticket counter, per-span counters); preset: it already holds
+// the all-ones pattern (kept by the caller across calls, see ecm_gn3d_fwd_p) -- otherwise it is memset here.
+int gn_fwd_impl(const float* x, const float* gamma, const float* beta, const float* skip, float* y, float* mean_rstd,
+                void* scratch, long long scratch_bytes, float* cluster, bool preset, int B, int C, long long S, int relu,
+                float eps, void* stream) {
     if (C % GROUPS != 0 || (long long)B * C > 65535) return ECM_EUNSUP;
     if (scratch_bytes < ecm_gn3d_scratch_bytes(B, C, S)) return ECM_ESCRATCH;
     if (const int pe = gn_pending_error()) return pe;
     hipStream_t st = ecm_stream(stream);
-    float* sc = static_cast<float*>(scratch);
     int rc;
-    if (relu && skip) rc = launch_fused_fwd<true, true>(x, gamma, beta, skip, y, mean_rstd, sc, B, C, S, eps, st);
-    else if (relu) rc = launch_fused_fwd<true, false>(x, gamma, beta, skip, y, mean_rstd, sc, B, C, S, eps, st);
-    else if (skip) rc = launch_fused_fwd<false, true>(x, gamma, beta, skip, y, mean_rstd, sc, B, C, S, eps, st);
-    else rc = launch_fused_fwd<false, false>(x, gamma, beta, skip, y, mean_rstd, sc, B, C, S, eps, st);
+    if (relu && skip) rc = launch_fused_fwd<true, true>(x, gamma, beta, skip, y, mean_rstd, cluster, preset, B, C, S, eps, st);
+    else if (relu) rc = launch_fused_fwd<true, false>(x, gamma, beta, skip, y, mean_rstd, cluster, preset, B, C, S, eps, st);
+    else if (skip) rc = launch_fused_fwd<false, true>(x, gamma, beta, skip, y, mean_rstd, cluster, preset, B, C, S, eps, st);
+    else rc = launch_fused_fwd<false, false>(x, gamma, beta, skip, y, mean_rstd, cluster, preset, B, C, S, eps, st);
     if (rc != -100) return rc;
     rc = ecm_gn3d_stats(x, mean_rstd, scratch, scratch_bytes, B, C, S, eps, stream);
     if (rc) return rc;
     return ecm_gn3d_apply(x, mean_rstd, gamma, beta, skip, y, B, C, S, relu, stream);
 }
 
-extern "C" int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
-                            const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
-                            long long scratch_bytes, int B, int C, long long S, int relu, void* stream) {
-    ECM_CHECK_ARG(x && mean_rstd && gamma && gy && gx && ggamma && gbeta && scratch && B > 0 && C > 0 && S > 0);
-    ECM_CHECK_ARG(!relu || y || beta);          // the ReLU mask comes from y, or is recomputed from x with beta
+int gn_bwd_impl(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
+                const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
+                long long scratch_bytes, float* cluster, bool preset, float* chan_fused, int B, int C, long long S, int relu,
+                void* stream) {
     if (C % GROUPS != 0 || (long long)B * C > 65535) return ECM_EUNSUP;
     if (scratch_bytes < ecm_gn3d_scratch_bytes(B, C, S)) return ECM_ESCRATCH;
     if (const int pe = gn_pending_error()) return pe;
     const int mask = !relu ? 0 : (y ? 1 : 2);
     hipStream_t st = ecm_stream(stream);
     float* sc = static_cast<float*>(scratch);
-    {   // fused: chan lives behind the cluster slots
-        float* chan = sc + fused_scratch_floats(B);
+    {
+        float* chan = chan_fused;
         int rc;
-        if (mask == 0) rc = gskip ? launch_fused_bwd<0, 1>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
-                                  : launch_fused_bwd<0, 0>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
-        else if (mask == 1) rc = gskip ? launch_fused_bwd<1, 1>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
-                                       : launch_fused_bwd<1, 0>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
-        else rc = gskip ? launch_fused_bwd<2, 1>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st)
-                        : launch_fused_bwd<2, 0>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, sc, B, C, S, st);
+        if (mask == 0) rc = gskip ? launch_fused_bwd<0, 1>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, cluster, preset, B, C, S, st)
+                                  : launch_fused_bwd<0, 0>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, cluster, preset, B, C, S, st);
+        else if (mask == 1) rc = gskip ? launch_fused_bwd<1, 1>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, cluster, preset, B, C, S, st)
+                                       : launch_fused_bwd<1, 0>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, cluster, preset, B, C, S, st);
+        else rc = gskip ? launch_fused_bwd<2, 1>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, cluster, preset, B, C, S, st)
+                        : launch_fused_bwd<2, 0>(x, mean_rstd, gamma, beta, y, gy, gx, gskip, chan, cluster, preset, B, C, S, st);
         if (rc == 0) {
             hipLaunchKernelGGL(gn_bwd_params, dim3((C + 63) / 64), dim3(64), 0, st, chan, ggamma, gbeta, B, C);
             return ECM_LAUNCH_RESULT();
@@ -835,4 +866,50 @@ extern "C" int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float*
     else if (mask == 1) hipLaunchKernelGGL(gn_bwd_apply<1>, g2, block, 0, st, x, mean_rstd, gamma, beta, y, gy, chan, gx, C, S);
     else hipLaunchKernelGGL(gn_bwd_apply<2>, g2, block, 0, st, x, mean_rstd, gamma, beta, y, gy, chan, gx, C, S);
     return ECM_LAUNCH_RESULT();
+}
+}  // namespace
+
+extern "C" int ecm_gn3d_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y,
+                            float* mean_rstd, void* scratch, long long scratch_bytes, int B, int C, long long S,
+                            int relu, float eps, void* stream) {
+    ECM_CHECK_ARG(x && gamma && beta && y && mean_rstd && scratch && B > 0 && C > 0 && S > 0);
+    return gn_fwd_impl(x, gamma, beta, skip, y, mean_rstd, scratch, scratch_bytes, static_cast<float*>(scratch), false, B, C, S,
+                       relu, eps, stream);
+}
+
+extern "C" int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
+                            const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
+                            long long scratch_bytes, int B, int C, long long S, int relu, void* stream) {
+    ECM_CHECK_ARG(x && mean_rstd && gamma && gy && gx && ggamma && gbeta && scratch && B > 0 && C > 0 && S > 0);
+    ECM_CHECK_ARG(!relu || y || beta);          // the ReLU mask comes from y, or is recomputed from x with beta
+    float* sc = static_cast<float*>(scratch);
+    return gn_bwd_impl(x, mean_rstd, gamma, beta, y, gy, gx, gskip, ggamma, gbeta, scratch, scratch_bytes, sc, false,
+                       sc + fused_scratch_floats(B), B, C, S, relu, stream);      // chan lives behind the cluster memory
+}
+
+extern "C" long long ecm_gn3d_cluster_bytes(int B) { return B > 0 ? fused_scratch_floats(B) * (long long)sizeof(float) : 0; }
+
+extern "C" int ecm_gn3d_cluster_preset(void* cluster, long long cluster_bytes, void* stream) {
+    ECM_CHECK_ARG(cluster && cluster_bytes > 0);
+    return (int)hipMemsetAsync(cluster, 0xff, (size_t)cluster_bytes, ecm_stream(stream));
+}
+
+extern "C" int ecm_gn3d_fwd_p(const float* x, const float* gamma, const float* beta, const float* skip, float* y,
+                              float* mean_rstd, void* scratch, long long scratch_bytes, void* cluster, long long cluster_bytes,
+                              int B, int C, long long S, int relu, float eps, void* stream) {
+    ECM_CHECK_ARG(x && gamma && beta && y && mean_rstd && scratch && cluster && B > 0 && C > 0 && S > 0);
+    if (cluster_bytes < ecm_gn3d_cluster_bytes(B)) return ECM_ESCRATCH;
+    return gn_fwd_impl(x, gamma, beta, skip, y, mean_rstd, scratch, scratch_bytes, static_cast<float*>(cluster), true, B, C, S,
+                       relu, eps, stream);
+}
+
+extern "C" int ecm_gn3d_bwd_p(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
+                              const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
+                              long long scratch_bytes, void* cluster, long long cluster_bytes, int B, int C, long long S,
+                              int relu, void* stream) {
+    ECM_CHECK_ARG(x && mean_rstd && gamma && gy && gx && ggamma && gbeta && scratch && cluster && B > 0 && C > 0 && S > 0);
+    ECM_CHECK_ARG(!relu || y || beta);
+    if (cluster_bytes < ecm_gn3d_cluster_bytes(B)) return ECM_ESCRATCH;
+    return gn_bwd_impl(x, mean_rstd, gamma, beta, y, gy, gx, gskip, ggamma, gbeta, scratch, scratch_bytes,
+                       static_cast<float*>(cluster), true, static_cast<float*>(scratch), B, C, S, relu, stream);
 }

@@ -865,6 +865,31 @@ def deconv3d_k3s2(x, w):
     return Deconv3dK3S2.apply(x, w)
 
 
+# Exchange memory of the one-pass GroupNorm kernels (cluster slots, ticket counter, per-span counters): kept per (device,
+# stream), preset once; the kernels hand it back in the preset state, so no memset precedes a launch (include/ecm_hip.h:
+# ecm_gn3d_fwd_p).  Dropped -- hence preset afresh -- whenever a call fails or an asynchronous time-out is reported.
+_GN_CLUSTER = {}
+
+
+def _gn_cluster(B, device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    nb = _lib.query("ecm_gn3d_cluster_bytes", B)
+    buf = _GN_CLUSTER.get(key)
+    if buf is None or buf.numel() < nb:
+        buf = torch.empty(max(int(nb), 1 << 20), dtype=torch.uint8, device=device)
+        _lib.call("ecm_gn3d_cluster_preset", _p(buf), C.c_longlong(buf.numel()), _stream())
+        _GN_CLUSTER[key] = buf
+    return buf
+
+
+def _gn_call(name, *args):
+    try:
+        _lib.call(name, *args)
+    except RuntimeError:
+        _GN_CLUSTER.clear()
+        raise
+
+
 class GroupNormAct(torch.autograd.Function):
     """y = relu?( GroupNorm32(x)*gamma+beta (+ skip) )  (cmfsm.py:58 + ReLU/residual at 287-299, 606-613, 685-693)."""
 
@@ -879,8 +904,9 @@ class GroupNormAct(torch.autograd.Function):
         nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
         scratch = _scratch(nb, x.device)
         y = _empty_like(x)
-        _lib.call("ecm_gn3d_fwd", _p(x), _p(gamma), _p(beta), _p(skip), _p(y), _p(stats), _p(scratch), C.c_longlong(nb),
-                  B, Cc, C.c_longlong(S), int(relu), C.c_float(GN_EPS), _stream())
+        cl = _gn_cluster(B, x.device)
+        _gn_call("ecm_gn3d_fwd_p", _p(x), _p(gamma), _p(beta), _p(skip), _p(y), _p(stats), _p(scratch), C.c_longlong(nb),
+                 _p(cl), C.c_longlong(cl.numel()), B, Cc, C.c_longlong(S), int(relu), C.c_float(GN_EPS), _stream())
         # ReLU mask in backward: recomputed from x unless a skip was added (then the output y is needed)
         ctx.save_for_backward(x, stats, gamma, beta, y if (relu and skip is not None) else None)
         ctx.relu, ctx.has_skip = relu, skip is not None
@@ -899,9 +925,10 @@ class GroupNormAct(torch.autograd.Function):
         ggamma, gbeta = _empty_like(gamma), _empty_like(gamma)
         nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
         scratch = _scratch(nb, x.device)
-        _lib.call("ecm_gn3d_bwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(gy), _p(gx),
-                  _p(gskip if (ctx.has_skip and ctx.relu) else None), _p(ggamma), _p(gbeta), _p(scratch),
-                  C.c_longlong(nb), B, Cc, C.c_longlong(S), int(ctx.relu), _stream())
+        cl = _gn_cluster(B, x.device)
+        _gn_call("ecm_gn3d_bwd_p", _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(gy), _p(gx),
+                 _p(gskip if (ctx.has_skip and ctx.relu) else None), _p(ggamma), _p(gbeta), _p(scratch),
+                 C.c_longlong(nb), _p(cl), C.c_longlong(cl.numel()), B, Cc, C.c_longlong(S), int(ctx.relu), _stream())
         return gx, ggamma, gbeta, gskip, None
 
 
@@ -1057,5 +1084,6 @@ def check_async_errors(clear=True):
     torch.cuda.synchronize()
     rc = _lib.query("ecm_async_status", 1 if clear else 0)
     if rc != 0:
+        _GN_CLUSTER.clear()                    # a timed-out cluster leaves the exchange memory in an unknown state
         msg = _lib.load().ecm_error_string(rc)
         raise RuntimeError(f"asynchronous device-side failure ({rc}): {msg.decode() if msg else '?'}")

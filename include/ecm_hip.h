@@ -243,6 +243,22 @@ int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, con
                  const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
                  long long scratch_bytes, int B, int C, long long S, int relu, void* stream);
 
+/* The same two calls for a caller that KEEPS the one-pass kernels' exchange memory across calls: `cluster` is a device
+ * buffer of >= ecm_gn3d_cluster_bytes(B) bytes that was filled once by ecm_gn3d_cluster_preset (all-ones) and is used by one
+ * stream at a time.  The kernels leave it in the preset state when they finish (the last member of a cluster restores the
+ * cluster's slots, the last ticket draw the ticket counter), so no memset is issued per launch (ecm_gn3d_fwd / _bwd issue one:
+ * 172 per cmfsm training step).  After an asynchronous time-out (ECM_EASYNC) the buffer must be preset again.  `scratch` as
+ * for ecm_gn3d_fwd / _bwd (two-stage partials and the per-channel sums). */
+long long ecm_gn3d_cluster_bytes(int B);
+int ecm_gn3d_cluster_preset(void* cluster, long long cluster_bytes, void* stream);
+int ecm_gn3d_fwd_p(const float* x, const float* gamma, const float* beta, const float* skip, float* y,
+                   float* mean_rstd, void* scratch, long long scratch_bytes, void* cluster, long long cluster_bytes,
+                   int B, int C, long long S, int relu, float eps, void* stream);
+int ecm_gn3d_bwd_p(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
+                   const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
+                   long long scratch_bytes, void* cluster, long long cluster_bytes, int B, int C, long long S,
+                   int relu, void* stream);
+
 /* Cost volume + dres0's first Conv3d (cmfsm.py:667-684) without the 4-D volume: both halves of the concat volume are
  * constant along a line in (d,x), so the 3x3x3 convolution collapses to 2-D convolutions of the feature maps (host side):
  *   P[b, classP, co, y, x]     classP(d,x) = (clamp(d-x,-2,2)+2)*3 + edge(d)        15 classes, reference-image half

@@ -91,3 +91,23 @@ def test_cluster_timeout_is_a_clean_error(ecm):
     y = ecm.ops.group_norm_act(x, gm, bt, None, False)
     torch.testing.assert_close(y, F.group_norm(x, 32, gm, bt, 1e-5), rtol=1e-4, atol=1e-5)
     ecm.ops.check_async_errors()
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 24, 144, 240), (8, 64, 144, 240), (1, 32, 8, 48, 96), (3, 128, 36, 60)])
+def test_exchange_memory_is_handed_back_preset(ecm, shape):
+    """The one-pass kernels restore their exchange memory (slots, ticket counter, per-span counters) to the all-ones preset
+    before they finish, so the copy `ops` keeps per (device, stream) needs no memset between launches: after forward and
+    backward, repeated, every byte of it is 0xFF again and the results stay correct."""
+    ops = ecm.ops
+    x, gm, bt = _case(sum(shape), shape)
+    ref = F.relu(F.group_norm(x, 32, gm, bt, 1e-5))
+    for rep in range(3):
+        xg = x.clone().requires_grad_()
+        y = ops.group_norm_act(xg, gm, bt, None, True)
+        y.backward(torch.ones_like(y))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y.detach(), ref, rtol=1e-4, atol=1e-5)
+        assert ops._GN_CLUSTER, "the cluster path keeps its exchange memory"
+        for buf in ops._GN_CLUSTER.values():
+            assert bool((buf == 0xFF).all()), f"exchange memory not restored after repetition {rep}"
+    ops.check_async_errors()

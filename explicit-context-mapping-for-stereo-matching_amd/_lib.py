@@ -45,6 +45,9 @@ PROTOTYPES = {
     "ecm_conv_wino_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_conv_wino_fwd_add": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_sum_n": (_I, [_P, _P, _P, _P, _P, _LL, _P]),
+    "ecm_zero_insert2d": (_I, [_P, _P, _LL, _I, _I, _I, _I, _P]),
+    "ecm_costvol_class_weights_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "ecm_costvol_class_weights_bwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "ecm_conv_wino_wgrad_scratch_bytes": (_LL, [_I] * 7),
     "ecm_conv_wino_wgrad": (_I, [_P, _P, _P, _P, _LL] + [_I] * 7 + [_P]),
     "ecm_conv3d_c1_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -133,6 +133,77 @@ __global__ __launch_bounds__(256) void costvol_conv_gq(const float* __restrict__
     o[4 * Co * hq] = last;  o[5 * Co * hq] = lastr;
 }
 
+
+// ---- class-indexed 2-D kernels of the collapsed first convolution (what ops.costvol_conv3d builds every step) ----------------
+// wP[x][co][ci][kh][kw]    = sum_kd mP[x][kd][kw]        w[co][ci][kd][kh][kw]         x = (clamp(d-x,-2,2)+2)*3 + edge, 15 classes
+// wQ[x][co][ci][kh][ku]    = sum_{kd,kw} mQ[x][kd][kw][ku] w[co][C+ci][kd][kh][kw]     x = edge*2 + (column == w-1), 6 classes
+// with the 0/1 tap masks of csrc/costvol_conv.hip's header (a tap passes the wedge `x >= d` / the depth padding; a passing
+// target-half tap lands on column ku = kw - kd + 2 of the sheared 3x5 kernel).  Backward: the transposed sums.
+__device__ __forceinline__ bool cls_depth_ok(int e, int kd) { return !((e == 0 && kd == 0) || (e == 2 && kd == 2)); }
+__device__ __forceinline__ bool cls_mp(int x, int kd, int kw) { return cls_depth_ok(x % 3, kd) && kw - kd >= x / 3 - 2; }
+__device__ __forceinline__ bool cls_mq(int x, int kd, int kw, int ku) {
+    return cls_depth_ok(x / 2, kd) && ku == kw - kd + 2 && ((x & 1) == 0 || kw != 2);
+}
+
+__global__ __launch_bounds__(256) void class_weights_fwd(const float* __restrict__ w, float* __restrict__ wP, float* __restrict__ wQ,
+                                                         int Co, int C) {
+    const int nP = 15 * Co * C * 9, nQ = 6 * Co * C * 15;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nP) {
+        int r = idx;
+        const int kw = r % 3; r /= 3;
+        const int kh = r % 3; r /= 3;
+        const int ci = r % C; r /= C;
+        const int co = r % Co;
+        const int x = r / Co;
+        float s = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+            if (cls_mp(x, kd, kw)) s += w[(((size_t)co * 2 * C + ci) * 3 + kd) * 9 + kh * 3 + kw];
+        wP[idx] = s;
+    } else if (idx < nP + nQ) {
+        int r = idx - nP;
+        const int ku = r % 5; r /= 5;
+        const int kh = r % 3; r /= 3;
+        const int ci = r % C; r /= C;
+        const int co = r % Co;
+        const int x = r / Co;
+        float s = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                if (cls_mq(x, kd, kw, ku)) s += w[(((size_t)co * 2 * C + C + ci) * 3 + kd) * 9 + kh * 3 + kw];
+        wQ[idx - nP] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void class_weights_bwd(const float* __restrict__ gwP, const float* __restrict__ gwQ,
+                                                         float* __restrict__ gw, int Co, int C) {
+    const int n = Co * 2 * C * 27;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int r = idx;
+    const int kw = r % 3; r /= 3;
+    const int kh = r % 3; r /= 3;
+    const int kd = r % 3; r /= 3;
+    const int cc = r % (2 * C);
+    const int co = r / (2 * C);
+    float s = 0.f;
+    if (cc < C) {
+#pragma unroll
+        for (int x = 0; x < 15; ++x)
+            if (cls_mp(x, kd, kw)) s += gwP[((((size_t)x * Co + co) * C + cc) * 3 + kh) * 3 + kw];
+    } else {
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+            for (int ku = 0; ku < 5; ++ku)
+                if (cls_mq(x, kd, kw, ku)) s += gwQ[((((size_t)x * Co + co) * C + (cc - C)) * 3 + kh) * 5 + ku];
+    }
+    gw[idx] = s;
+}
+
 }  // namespace
 
 extern "C" int ecm_costvol_conv_assemble_fwd(const float* P, const float* Qp, float* y, int B, int Co, int D, int h, int w,
@@ -160,5 +231,21 @@ extern "C" int ecm_costvol_conv_assemble_bwd(const float* gy, float* gP, float* 
     const long long tp = (long long)B * Co * h * w, tq = (long long)B * Co * h * (w + 2);
     hipLaunchKernelGGL(costvol_conv_gp, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, st, gy, gP, Co, D, h, w, tp);
     hipLaunchKernelGGL(costvol_conv_gq, dim3((unsigned)((tq + 255) / 256)), dim3(256), 0, st, gy, gQp, Co, D, h, w, tq);
+    return ECM_LAUNCH_RESULT();
+}
+
+extern "C" int ecm_costvol_class_weights_fwd(const float* w, float* wP, float* wQ, int Co, int C, void* stream) {
+    ECM_CHECK_ARG(w && wP && wQ && Co > 0 && C > 0);
+    const long long n = (long long)Co * C * (15 * 9 + 6 * 15);
+    if (n > 0x7fffffffLL) return ECM_EUNSUP;
+    hipLaunchKernelGGL(class_weights_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ecm_stream(stream), w, wP, wQ, Co, C);
+    return ECM_LAUNCH_RESULT();
+}
+
+extern "C" int ecm_costvol_class_weights_bwd(const float* gwP, const float* gwQ, float* gw, int Co, int C, void* stream) {
+    ECM_CHECK_ARG(gwP && gwQ && gw && Co > 0 && C > 0);
+    const long long n = (long long)Co * 2 * C * 27;
+    if (n > 0x7fffffffLL) return ECM_EUNSUP;
+    hipLaunchKernelGGL(class_weights_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ecm_stream(stream), gwP, gwQ, gw, Co, C);
     return ECM_LAUNCH_RESULT();
 }

@@ -28,7 +28,33 @@ __global__ __launch_bounds__(256) void sum_n_kernel(const float* __restrict__ a,
     }
 }
 
+// out[b,c,y,x] = (y, x both even) ? small[b,c,y/2,x/2] : 0 -- the data gradient of a 1x1 / stride-2 projection (the encoder's
+// downsample layers, cmfsm.py:72-75 via _make_layer) after W^T gy has been formed on the coarse grid: one write pass
+__global__ __launch_bounds__(256) void zero_insert2_kernel(const float* __restrict__ small, float* __restrict__ out, long long planes,
+                                                           int H, int W, int Hs, int Ws) {
+    const long long n = planes * H * W;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int x = (int)(i % W);
+        const long long r = i / W;
+        const int y = (int)(r % H);
+        const long long p = r / H;
+        float v = 0.f;
+        if (((x | y) & 1) == 0 && (y >> 1) < Hs && (x >> 1) < Ws) v = small[(p * Hs + (y >> 1)) * Ws + (x >> 1)];
+        out[i] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int ecm_zero_insert2d(const float* small, float* out, long long planes, int H, int W, int Hs, int Ws, void* stream) {
+    ECM_CHECK_ARG(small && out && planes > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0);
+    const long long n = planes * H * W;
+    const long long want = (n + 255) / 256;
+    hipLaunchKernelGGL(zero_insert2_kernel, dim3((unsigned)(want > 256 * 16 ? 256 * 16 : want)), dim3(256), 0, ecm_stream(stream), small,
+                       out, planes, H, W, Hs, Ws);
+    return ECM_LAUNCH_RESULT();
+}
 
 extern "C" int ecm_sum_n(const float* a, const float* b, const float* c, const float* d, float* out, long long n, void* stream) {
     ECM_CHECK_ARG(a && b && out && n > 0 && (c || !d));

@@ -107,32 +107,30 @@ class CostvolConvAssemble(torch.autograd.Function):
         return gP, gQ, None
 
 
-_CLASS_TAPS = {}
+class ClassWeights(torch.autograd.Function):
+    """dres0[0][0].weight [Co,2C,3,3,3] -> (wP [15*Co,C,3,3], wQ [6*Co,C,3,5]): the class-indexed 2-D kernels of the collapsed
+    first convolution (csrc/costvol_conv.hip).  Class = which taps pass the wedge `x >= d` of cmfsm.py:678-679 and the depth
+    padding: reference half (clamp(d-x,-2,2)+2)*3 + edge with edge = 0 / 1 / 2 for the first / an interior / the last
+    disparity plane; target half edge*2 + (x == w-1), a passing tap landing on column kw-kd+2 of the sheared 3x5 kernel."""
 
+    @staticmethod
+    def forward(ctx, w):
+        _chk(w)
+        w = _c(w)
+        Co, C2 = w.shape[:2]
+        Cc = C2 // 2
+        wP = torch.empty(15 * Co, Cc, 3, 3, device=w.device, dtype=w.dtype)
+        wQ = torch.empty(6 * Co, Cc, 3, 5, device=w.device, dtype=w.dtype)
+        _lib.call("ecm_costvol_class_weights_fwd", _p(w), _p(wP), _p(wQ), Co, Cc, _stream())
+        ctx.dims = (Co, Cc)
+        return wP, wQ
 
-def _class_tap_masks(device):
-    """0/1 tap-selection tensors of the two halves of the concat volume (csrc/costvol_conv.hip):
-    mP [15, kd, kw]      reference half: class = (clamp(d-x,-2,2)+2)*3 + edge; a tap passes iff kw-kd >= d-x (the wedge
-                         `x >= d` of cmfsm.py:678-679 at the tap's position) and 0 <= d+kd-1 < D (depth padding);
-    mQ [6, kd, kw, ku]   target half: class = edge*2 + (x == w-1); a passing tap (depth padding; kw != 2 on the right
-                         border) lands on column ku = kw-kd+2 of the sheared 3x5 kernel.
-    edge = 0 / 1 / 2 for the first / an interior / the last disparity plane."""
-    m = _CLASS_TAPS.get(device)
-    if m is None:
-        mP, mQ = torch.zeros(15, 3, 3), torch.zeros(6, 3, 3, 5)
-        for e in range(3):
-            for kd in range(3):
-                if (e == 0 and kd == 0) or (e == 2 and kd == 2):
-                    continue
-                for kw in range(3):
-                    for dc in range(5):
-                        if kw - kd >= dc - 2:
-                            mP[dc * 3 + e, kd, kw] = 1.0
-                    mQ[e * 2 + 0, kd, kw, kw - kd + 2] = 1.0
-                    if kw != 2:
-                        mQ[e * 2 + 1, kd, kw, kw - kd + 2] = 1.0
-        m = _CLASS_TAPS[device] = (mP.to(device), mQ.to(device))
-    return m
+    @staticmethod
+    def backward(ctx, gwP, gwQ):
+        Co, Cc = ctx.dims
+        gw = torch.empty(Co, 2 * Cc, 3, 3, 3, device=gwP.device, dtype=gwP.dtype)
+        _lib.call("ecm_costvol_class_weights_bwd", _p(_c(gwP)), _p(_c(gwQ)), _p(gw), Co, Cc, _stream())
+        return gw
 
 
 def costvol_conv3d(left, right, weight, ndisp):
@@ -143,10 +141,7 @@ def costvol_conv3d(left, right, weight, ndisp):
     Cc = left.shape[1]
     if weight.shape[1] != 2 * Cc or ndisp < 2:
         return conv3d_k3(cost_volume(left, right, ndisp), weight, 1)
-    Co = weight.shape[0]
-    mP, mQ = _class_tap_masks(weight.device)
-    wP = torch.einsum("xdk,oidhk->xoihk", mP, weight[:, :Cc]).reshape(15 * Co, Cc, 3, 3)
-    wQ = torch.einsum("xdkq,oidhk->xoihq", mQ, weight[:, Cc:]).reshape(6 * Co, Cc, 3, 5)
+    wP, wQ = ClassWeights.apply(weight)
     h, w = left.shape[-2:]
     P = conv2d(left, wP, 1, 1, 1, 1, h, w)                      # 3x3, pad 1                                  [B,15Co,h,w]
     # sheared 3x5 on the target features with 2 extra zero columns on the left: pad (1, 2) of F.pad(right, (2, 0)) is a
@@ -753,8 +748,8 @@ class Conv2dG(torch.autograd.Function):
             else:
                 # 1x1, stride 2 (the downsample projections): W^T gy lands on the even positions, zeros elsewhere
                 small = _conv2d_run(gy, _pack2d(w, True), Ci, 1, 1, 1, 1, 0, 0, Ho, Wo)
-                gx = torch.zeros(B, Ci, H, W, device=x.device, dtype=x.dtype)
-                gx[:, :, ::2, ::2] = small
+                gx = torch.empty(B, Ci, H, W, device=x.device, dtype=x.dtype)
+                _lib.call("ecm_zero_insert2d", _p(small), _p(gx), C.c_longlong(B * Ci), H, W, Ho, Wo, _stream())
             gx = _fork_grad(gx, gskip)
         if ctx.needs_input_grad[1] and ctx.wino_same and _wino_ok(x) and WINOGRAD_WGRAD:
             gw = _wino_wgrad(x, gy, Co, Ci, 1)

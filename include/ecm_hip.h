@@ -146,6 +146,9 @@ int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int
  * several consumers in one pass (cmfsm.py:686-693: cost0 feeds the first hourglass and three residual adds) instead of
  * autograd's chain of binary adds.  16-byte aligned pointers; out may alias an input. */
 int ecm_sum_n(const float* a, const float* b, const float* c, const float* d, float* out, long long n, void* stream);
+/* out [planes,H,W] = small [planes,Hs,Ws] on the even positions, 0 elsewhere: the data gradient of a 1x1 / stride-2 projection
+ * (the encoder's downsample layers) once W^T gy exists on the coarse grid. */
+int ecm_zero_insert2d(const float* small, float* out, long long planes, int H, int W, int Hs, int Ws, void* stream);
 
 /* y = conv(x) + addend, addend shaped like y and added in the kernel's epilogue: with the data-gradient weights this is
  * autograd's accumulation at a skip connection (gx = dgrad(gy) + g_skip; BasicBlock cmfsm.py:76-85, dres1 612-613, the
@@ -242,6 +245,12 @@ int ecm_async_status(int clear);
 int ecm_gn3d_bwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* y,
                  const float* gy, float* gx, float* gskip, float* ggamma, float* gbeta, void* scratch,
                  long long scratch_bytes, int B, int C, long long S, int relu, void* stream);
+
+/* The class-indexed 2-D kernels of that collapse from dres0[0][0].weight w [Co,2C,3,3,3] (reference layout):
+ * wP [15,Co,C,3,3] (one 3x3 kernel per (wedge class, depth-edge class) of the reference-image half) and wQ [6,Co,C,3,5]
+ * (sheared 3x5 kernels of the target-image half); bwd: gw from (gwP, gwQ), every element written. */
+int ecm_costvol_class_weights_fwd(const float* w, float* wP, float* wQ, int Co, int C, void* stream);
+int ecm_costvol_class_weights_bwd(const float* gwP, const float* gwQ, float* gw, int Co, int C, void* stream);
 
 /* The same two calls for a caller that KEEPS the one-pass kernels' exchange memory across calls: `cluster` is a device
  * buffer of >= ecm_gn3d_cluster_bytes(B) bytes that was filled once by ecm_gn3d_cluster_preset (all-ones) and is used by one

@@ -670,6 +670,36 @@ def test_class_convolutions_vs_torch(ecm, B, C, h, w):
         close(wg.grad, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))
 
 
+def test_class_weight_kernels_vs_mask_einsum(ecm):
+    """ops.ClassWeights (the class-indexed kernels of the collapsed first convolution, cmfsm.py:667-684) against the 0/1 tap
+    masks written out in plain torch, forward and backward."""
+    mP, mQ = torch.zeros(15, 3, 3), torch.zeros(6, 3, 3, 5)
+    for e in range(3):
+        for kd in range(3):
+            if (e == 0 and kd == 0) or (e == 2 and kd == 2):
+                continue                                     # depth padding at the first / last disparity plane
+            for kw in range(3):
+                for dc in range(5):
+                    if kw - kd >= dc - 2:                    # the wedge `x >= d` at the tap's position, class dc = clamp(d-x,-2,2)+2
+                        mP[dc * 3 + e, kd, kw] = 1.0
+                mQ[e * 2 + 0, kd, kw, kw - kd + 2] = 1.0
+                if kw != 2:
+                    mQ[e * 2 + 1, kd, kw, kw - kd + 2] = 1.0   # right border column: the tap to the right is outside
+    Co, C = 8, 12
+    w = seeded("cw.w", Co, 2 * C, 3, 3, 3)
+    ws = w.clone().requires_grad_()
+    rP = torch.einsum("xdk,oidhk->xoihk", mP, ws[:, :C]).reshape(15 * Co, C, 3, 3)
+    rQ = torch.einsum("xdkq,oidhk->xoihq", mQ, ws[:, C:]).reshape(6 * Co, C, 3, 5)
+    GP, GQ = seeded("cw.GP", *rP.shape), seeded("cw.GQ", *rQ.shape)
+    ((rP * GP).sum() + (rQ * GQ).sum()).backward()
+    wg = dev(w).requires_grad_()
+    wP, wQ = ecm.ops.ClassWeights.apply(wg)
+    ((wP * dev(GP)).sum() + (wQ * dev(GQ)).sum()).backward()
+    close(wP, rP.detach(), 1e-6, 1e-7)
+    close(wQ, rQ.detach(), 1e-6, 1e-7)
+    close(wg.grad, ws.grad, 1e-5, 1e-6)
+
+
 def test_no_miopen_convolution_in_the_model(ecm):
     """SURVEY 8f n2 / VERDICT r1: no convolution of the registered architectures is left on PyTorch-ROCm (MIOpen)."""
     mdl = importlib.import_module("explicit-context-mapping-for-stereo-matching_amd.models")

@@ -89,10 +89,16 @@ def test_full_cmfsm_train_step_against_fp64_reference(ecm):
     print("worst norm-error ratios vs the yardstick:", worst)
 
 
-def test_cmfsm_sub_16_hot_path_against_fp64_reference(ecm):
-    """Post-encoder path of cmfsm_sub_16 (six-related weights on both images + the fused volume-mapping head,
-    cmfsm_sub_16.py:722-850): predictions, feature gradients and every parameter's gradient vs the reference in fp64."""
-    arch, s, h, w = "cmfsm_sub_16", 16, 4, 4
+_ARCHS64 = {"cmfsm_sub_16": (16, 4, 4, 8), "bilinear_cmf_sub_16": (16, 4, 4, 4), "cmfsm_sub_8": (8, 4, 8, 8)}   # s, h, w, full tensors
+
+
+@pytest.mark.parametrize("arch", sorted(_ARCHS64))
+def test_arch_hot_path_against_fp64_reference(ecm, arch):
+    """Post-encoder path of three more registered architectures behind the stub encoder -- cmfsm_sub_16 (six-related weights
+    on both images + the fused volume-mapping head, cmfsm_sub_16.py:722-850), bilinear_cmf_sub_16 (test.py:111's default:
+    trilinear soft-argmin head, bilinear_cmf.py:447-471) and cmfsm_sub_8 (5-neighbour aggregation, cmfsm_sub_8.py:440-572):
+    predictions, feature gradients and every parameter's gradient vs the reference run in fp64."""
+    s, h, w, min_full = _ARCHS64[arch]
     z = _z(f"arch_{arch}_fp64")
     model = ecm.get_model(arch)
     sd = {k: tensor_for(k, v.shape) for k, v in model.state_dict().items() if not k.startswith("feature_extraction")}
@@ -106,11 +112,17 @@ def test_cmfsm_sub_16_hot_path_against_fp64_reference(ecm):
     for i, p in enumerate(preds, 1):
         d = (p.detach().double().cpu() - torch.from_numpy(z[f"pred{i}_64"])).abs()
         assert float(d.max()) <= 2e-2 and float(d.mean()) <= 1e-3, (i, float(d.max()), float(d.mean()))
+    n_feat = 0
     for nm, t in zip(("g_lr_l", "g_hr_l", "g_lr_r", "g_hr_r"), feats):
+        if nm + "_64" not in z:                                  # the reference leaves this feature map unused ...
+            assert t.grad is None or float(t.grad.abs().max()) == 0.0, nm   # ... and so does the HIP path
+            continue
         t64 = torch.from_numpy(z[nm + "_64"])
         e = (t.grad.double().cpu() - t64).abs()
         assert float(e.max()) <= K * float(z["e32max_" + nm]) + FLOOR * float(t64.abs().max()), \
             (nm, float(e.max()), float(z["e32max_" + nm]), float(t64.abs().max()))
+        n_feat += 1
+    assert n_feat >= 2, n_feat
     n_full, worst = _check_params(model, z, arch, skip_prefix="feature_extraction")
-    assert n_full >= 8, n_full
+    assert n_full >= min_full, n_full
     print("worst norm-error ratios vs the yardstick:", worst)

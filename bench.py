@@ -251,12 +251,18 @@ def main():
     # event-timed per launch on the launch stream (torch's current stream, the one every kernel of the step is launched on)
     TIMED = ("ecm_conv_wino_fwd", "ecm_conv3d_k3_fwd", "ecm_conv3d_k3_wgrad", "ecm_conv3d_c1_fwd", "ecm_weights9_fwd",
              "ecm_weights9_bwd", "ecm_deconv3d_k3s2_fwd")
+    # The timed steps run the weight gradients on a second stream, under the data-gradient / GroupNorm chain (ops._on_side):
+    # a launch then shares the device and its duration says nothing about the kernel.  For this pass they go back onto the
+    # main stream, so every timed launch has the device to itself (profiles/: the kernel stats of a run with
+    # ECM_WGRAD_OVERLAP=0 are the ones these averages agree with).
+    overlap_was = ops.enable_wgrad_overlap(False)
     for name in TIMED:
         lib.enable_timer(name)
     for _ in range(min(args.steps, 5)):                    # every rank: the training step holds a collective
         step()
     torch.cuda.synchronize()
     timers = lib.disable_timers()
+    ops.enable_wgrad_overlap(overlap_was)
     ops.check_async_errors()                               # a GroupNorm cluster time-out during the timed steps is fatal
     last = step()                                          # outside the timed region: the result must be finite
     assert bool(torch.isfinite(last).all()), "non-finite loss / disparity after the timed steps"
@@ -519,7 +525,9 @@ def main():
                          "executed_over_algorithmic": executed,
                          "traffic": traffic_conv, "traffic_note": traffic_note,
                          "launches_timed": len(sel), "avg_launch_ms": conv_ms,
-                         "timing": "HIP events per launch on the launch stream, second pass after the timed steps",
+                         "timing": "HIP events per launch on the launch stream, second pass after the timed steps with the weight "
+                                   "gradients back on the main stream (in the timed steps they overlap the rest of backward on a "
+                                   "second stream: %s)" % ("on" if overlap_was else "off"),
                          "of_which_32to32": {"achieved": main_tf * executed, "frac": main_tf * executed / PEAK_F32_MFMA_TFLOPS,
                                              "algorithmic_equiv": main_tf,
                                              "avg_launch_ms": main_ms, "launches_timed": len(main_l)}},

@@ -403,9 +403,17 @@ struct FusedCtl {
 // (all-ones) state, and the workgroup that draws the very last ticket of the launch does the same for the ticket counter.
 // A launch that ends without a time-out therefore leaves the exchange memory exactly as it found it, and a caller that
 // keeps it across calls (ecm_gn3d_fwd_p / _bwd_p) needs no memset per launch (172 per training step before).
-__device__ __forceinline__ bool cluster_done(const FusedCtl& ctl, const Tickets& tk, int span, int cl, unsigned tnext) {
-    if (tk.dynamic && tnext == tk.total + tk.stride - 1u)            // the last draw of the launch (stride == gridDim.x)
+// Every workgroup of the launch draws until it gets a ticket >= total, i.e. total + gridDim.x draws in all; whoever makes the
+// last one puts the counter back.  That can be a workgroup's FIRST draw -- one the dispatcher placed only after the others had
+// worked through every ticket (another stream's kernels held its CU): such a workgroup never enters the ticket loop, so the
+// check sits on both draws.  (Found when weight gradients were moved to a second stream: the counter stayed at total + grid - 1,
+// the next launch started in the middle of its ticket range, and its clusters waited for members nobody would ever be.)
+__device__ __forceinline__ void ticket_drawn(const FusedCtl& ctl, const Tickets& tk, unsigned t) {
+    if (tk.dynamic && t == tk.total + tk.stride - 1u)                 // the last draw of the launch (stride == gridDim.x)
         __hip_atomic_store(ctl.ticket, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool cluster_done(const FusedCtl& ctl, const Tickets& tk, int span, int cl, unsigned tnext) {
+    ticket_drawn(ctl, tk, tnext);
     const unsigned old = atomicAdd(ctl.done + span, 1u);              // preset 0xFFFFFFFF: the k-th arrival reads k - 2
     return old + 2u == (unsigned)cl;
 }
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
     const long long nv4 = S >> 2;                       // < 2^31 (checked by the host): 32-bit indices within a channel
     const unsigned toff = (unsigned)(wave * MAXV4 * 64 + lane) * 16u;     // wave-contiguous rows of 64 float4 (1 KB)
     const Tickets tk{ctl.ticket, (unsigned)nspans * (unsigned)cl, gridDim.x, ctl.dynamic != 0};
-    if (tid == 0) tick_s = tk.first();
+    if (tid == 0) { tick_s = tk.first(); if (tick_s >= tk.total) ticket_drawn(ctl, tk, tick_s); }
     __syncthreads();
     unsigned t = tick_s;
     while (t < tk.total) {
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
     const long long nv4 = S >> 2;                       // < 2^31 (checked by the host): 32-bit indices within a channel
     const unsigned toff = (unsigned)(wave * MAXV4 * 64 + lane) * 16u;     // wave-contiguous rows of 64 float4 (1 KB)
     const Tickets tk{ctl.ticket, (unsigned)nspans * (unsigned)cl, gridDim.x, ctl.dynamic != 0};
-    if (tid == 0) tick_s = tk.first();
+    if (tid == 0) { tick_s = tk.first(); if (tick_s >= tk.total) ticket_drawn(ctl, tk, tick_s); }
     __syncthreads();
     unsigned t = tick_s;
     while (t < tk.total) {

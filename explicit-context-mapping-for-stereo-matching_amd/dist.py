@@ -61,8 +61,14 @@ class FlatBucketDDP:
     so that the SUM of the ranks' gradients is the gradient of the global masked mean; allreduce_gradients() then sums
     without dividing.  Without it, gradients are averaged (equal-count shards)."""
 
-    def __init__(self, module: torch.nn.Module, world: int | None = None, late_module: str | None = "feature_extraction"):
+    def __init__(self, module: torch.nn.Module, world: int | None = None, late_module: str | None = "feature_extraction",
+                 overlap_wgrad: bool = True):
         self.module = module
+        if overlap_wgrad and next(module.parameters()).is_cuda:
+            # this class owns every reader of the weight gradients (the bucket gather; the optimizer behind
+            # allreduce_gradients()), and joins the side stream before both: weight gradients may run there (ops._on_side)
+            from . import ops
+            ops.enable_wgrad_overlap(True)
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         named = [(k, p) for k, p in module.named_parameters() if p.requires_grad]
         late = getattr(module, late_module, None) if late_module else None
@@ -153,6 +159,9 @@ class FlatBucketDDP:
         return grad
 
     def _gather(self, lo: int, hi: int):
+        if self.flat.is_cuda:
+            from . import ops
+            ops.join_side_streams()                   # weight gradients are computed on a side stream (ops._on_side)
         dst, src, unused = [], [], []
         for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             if p.grad is None:
@@ -184,7 +193,7 @@ class FlatBucketDDP:
         """Gather the step's gradients into the bucket, sum over ranks (average unless global_mean_loss pre-scaled the loss),
         and leave every .grad pointing at its slice of the bucket for the optimizer."""
         early_done = self._early_work is not None
-        self._gather(0, self.n_late if early_done else len(self.params))
+        self._gather(0, self.n_late if early_done else len(self.params))      # (joins the weight-gradient stream first)
         if self.world > 1:
             if early_done:
                 if self.n_late:

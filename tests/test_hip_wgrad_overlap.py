@@ -1,0 +1,79 @@
+"""Weight gradients on a side stream (ops._on_side): same gradients bit for bit, and the GroupNorm cluster kernels keep working
+while another stream's kernels hold CUs (the ticket counter of gn3d.hip used to stay un-reset when a workgroup was placed
+only after all tickets had gone -- found through exactly this configuration)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ecm():
+    assert torch.cuda.is_available()
+    import ecm_amd
+    return ecm_amd
+
+
+def _step(ecm, model, left, right, gt):
+    from importlib import import_module
+    D = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
+    for p in model.parameters():
+        p.grad = None
+    loss = D.masked_smooth_l1_x3(model(left, right), gt)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert ecm.ops._lib.query("ecm_async_status", 1) == 0, "a GroupNorm cluster launch timed out"
+    return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def test_side_stream_weight_gradients_are_bit_identical(ecm):
+    ops = ecm.ops
+    torch.manual_seed(3)
+    model = ecm.get_model("cmfsm").cuda().train()
+    B, H, W = 2, 576, 960
+    left, right = torch.randn(B, 3, H, W, device="cuda"), torch.randn(B, 3, H, W, device="cuda")
+    gt = torch.rand(B, H, W, device="cuda") * 191
+    prev = ops.enable_wgrad_overlap(False)
+    try:
+        ref = _step(ecm, model, left, right, gt)
+        ops.enable_wgrad_overlap(True)
+        if not ops.WGRAD_OVERLAP:
+            pytest.skip("ECM_WGRAD_OVERLAP=0 in the environment")
+        for _ in range(3):                                     # several passes: the side stream's queue builds up
+            got = _step(ecm, model, left, right, gt)
+        assert ops._SIDE, "no weight gradient went to the side stream"
+        assert got.keys() == ref.keys()
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+    finally:
+        ops.enable_wgrad_overlap(prev)
+
+
+def test_non_leaf_and_hooked_weights_stay_on_the_main_stream(ecm):
+    """A weight that is the output of another op (its gradient flows on during the pass) or carries a tensor hook must not be
+    computed on the side stream."""
+    ops = ecm.ops
+    prev = ops.enable_wgrad_overlap(True)
+    try:
+        if not ops.WGRAD_OVERLAP:
+            pytest.skip("ECM_WGRAD_OVERLAP=0 in the environment")
+        ops._SIDE.clear()
+        x = torch.randn(1, 32, 8, 16, 32, device="cuda", requires_grad=True)
+        base = (torch.randn(32, 32, 3, 3, 3, device="cuda") * 0.05).requires_grad_()
+        w = base * 2.0                                         # non-leaf
+        ops.conv3d_k3(x, w, 1).sum().backward()
+        assert not ops._SIDE
+        seen = []
+        leaf = (torch.randn(32, 32, 3, 3, 3, device="cuda") * 0.05).requires_grad_()
+        leaf.register_hook(lambda g: seen.append(float(g.abs().sum())))
+        ops.conv3d_k3(x, leaf, 1).sum().backward()
+        assert not ops._SIDE and len(seen) == 1
+        ref = torch.autograd.grad(torch.nn.functional.conv3d(x, leaf.detach().requires_grad_(), padding=1).sum(), x)[0]
+        plain = (leaf.detach().clone()).requires_grad_()
+        ops.conv3d_k3(x, plain, 1).sum().backward()            # leaf, no hook: side stream
+        assert ops._SIDE
+        torch.cuda.synchronize()
+        assert torch.allclose(plain.grad, leaf.grad, rtol=0, atol=0)
+        assert ref.shape == x.shape
+    finally:
+        ops.enable_wgrad_overlap(prev)

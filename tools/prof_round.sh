@@ -6,6 +6,10 @@ cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/prof_r3
 rm -rf $O; mkdir -p $O
 echo stats; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+# the same run with the weight gradients on the main stream: every launch has the device to itself (what bench.py's roofline times)
+export ECM_WGRAD_OVERLAP=0
+echo stats unshared; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_unshared -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_under_rocprof_unshared.json 2> $O/bench_under_rocprof_unshared.err
+unset ECM_WGRAD_OVERLAP
 P="rocprofv3 --kernel-trace --output-format csv"
 echo calib; $P --pmc FETCH_SIZE -d $O/calib_fetch -- $R/tools/micro/fetch_calib > /dev/null 2>&1
 $P --pmc WRITE_SIZE -d $O/calib_write -- $R/tools/micro/fetch_calib > /dev/null 2>&1
@@ -22,6 +26,7 @@ cd $R
 python3 tools/pmc_traffic.py $O > $O/pmc_traffic.json
 python3 tools/pmc_mfma_summary.py wino=$O/mfma_wino wino_wgrad=$O/mfma_wino_wgrad ecmw_bwd=$O/mfma_ecmw_bwd > $O/pmc_mfma_util.json
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+cp $(ls $O/stats_unshared/*/*kernel_stats.csv | head -1) $O/kernel_stats_unshared.csv
 # keep the merged output small: drop the raw traces
 find $O -name "*kernel_trace.csv" -size +2M -delete
 find $O -name "*.db" -delete

@@ -8,10 +8,154 @@
 //             covers all 32 x 27 products; the tap shift is a per-lane LDS offset on the small gy tile)
 // Both are then bound by reading x once (212 MB at 576x960) instead of by ~92 GFLOP of padded MFMA work.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------ forward, vector-ALU form
+// 864 multiply-adds per output voxel is 5.7 G FMA for the batch-4 volume: 0.07 ms at the packed fp32 rate, under the 0.15-0.18 ms
+// it takes to read x once -- while the matrix-core form below pads 27 taps to 32 and pays a load -> LDS -> MFMA -> LDS -> 27 reads
+// chain per plane (0.31 ms).  Here every thread owns 2 x 2 x 4 outputs and walks the input channels TWO at a time: the halo tile
+// of a channel pair sits in LDS interleaved [position][2 channels], so a v_pk_fma_f32 multiplies the pair (x_c0, x_c1)[pos] by
+// the pair (w_c0, w_c1)[tap] into a pair of partial sums (added at the end) -- packed FMAs at full rate without any of the
+// register-pair alignment problems packing along w would have (a tap shift just selects another pair register).
+// Workgroup: 8 x 8 x 4 threads = 32 x 16 x 8 outputs; halo 34 x 18 x 10 per channel (1.49x, served by L2); the next pair's halo
+// is prefetched through registers while the current one is multiplied; 49.0 + 3.4 KB of LDS, two workgroups per CU.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int VT_W = 32, VT_H = 16, VT_D = 8;
+constexpr int VH_W = VT_W + 2, VH_H = VT_H + 2, VH_D = VT_D + 2;
+// LDS row = 34 positions + 2 of padding; rows hy with (hy >> 1) odd are shifted by 2 positions (4 dwords): the 64 lanes of a
+// window read (8 w-strips x 8 row pairs, 16 bytes each) then start at 8 different bank groups instead of 4 -- conflict-free
+constexpr int VROW = 36;
+constexpr int VPOS = VH_D * VH_H * VH_W;                   // 6120 halo positions
+constexpr int VSLOTS = (VPOS + 255) / 256;                 // 24 per thread
+constexpr int V_X_FLOATS = VH_D * VH_H * VROW * 2;
+constexpr int V_W_FLOATS = 16 * 27 * 2;
+constexpr int V_LDS_BYTES = (V_X_FLOATS + V_W_FLOATS + 2) * 4;   // + the scratch slot of the unused 24th halo slot
+static_assert(2 * V_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+__device__ __forceinline__ int v_slot(int dz, int hy, int wx) { return ((dz * VH_H + hy) * VROW + wx + 2 * ((hy >> 1) & 1)) * 2; }
+
+__global__ __launch_bounds__(256, 2) void conv3d_c1_fwd_v(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, int Ci, int D, int H, int W, int tiles_d,
+                                                          int tiles_h, int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                       // [VH_D][VH_H][VROW][2]
+    float* Ws = smem + V_X_FLOATS;          // [pair][27][2]
+    // depth fastest: the tiles an XCD works on at one time then share their depth halo (2 of 10 planes) through its L2, the most
+    // expensive one to re-read; the in-plane halo is shared with the next tiles of the run
+    int bid = ecm_xcd_tile(blockIdx.x, gridDim.x);
+    const int td = bid % tiles_d; bid /= tiles_d;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h;
+    const int b = bid / tiles_h;
+    const int w0 = tw * VT_W, h0 = th * VT_H, d0 = td * VT_D;
+    const int tid = threadIdx.x;
+    const int lw = tid & 7, lh = (tid >> 3) & 7, ld = tid >> 6;
+    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
+    const int npairs = Ci >> 1;
+
+    // weights, interleaved by channel pair
+    for (int i = tid; i < Ci * 27; i += 256) {
+        const int c = i / 27, tap = i - c * 27;
+        Ws[((c >> 1) * 27 + tap) * 2 + (c & 1)] = w[i];
+    }
+    // halo slots of this thread: global byte offset within a channel (out of range: dropped by the descriptor) and LDS slot
+    unsigned goff[VSLOTS];
+    int lslot[VSLOTS];
+#pragma unroll
+    for (int k = 0; k < VSLOTS; ++k) {
+        const int p = tid + 256 * k;
+        const int dz = p / (VH_H * VH_W), r = p - dz * (VH_H * VH_W), hy = r / VH_W, wx = r - hy * VH_W;
+        const int gz = d0 - 1 + dz, gy = h0 - 1 + hy, gx = w0 - 1 + wx;
+        const bool ok = p < VPOS && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        goff[k] = ok ? (unsigned)(((size_t)gz * H + gy) * W + gx) * 4u : 0x80000000u;
+        lslot[k] = p < VPOS ? v_slot(dz, hy, wx) * 4 : (V_X_FLOATS + V_W_FLOATS) * 4;   // bytes; past the end: a scratch slot nobody reads
+        asm volatile("" : "+v"(goff[k]), "+v"(lslot[k]));   // keep them in registers: recomputing costs more than the pk_fmas
+    }
+    const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)b * Ci * DHW, 0,
+                                                      (unsigned)((size_t)Ci * DHW * 4), 0x00020000);
+    const unsigned cstride = (unsigned)(DHW * 4);
+    f32x2 rr[VSLOTS];                                        // (channel 2p, channel 2p+1) of a halo position: one ds_write_b64
+    auto fetch = [&](int pair) {
+        const unsigned s0 = (unsigned)(2 * pair) * cstride;
+#pragma unroll
+        for (int k = 0; k < VSLOTS; ++k) {
+            rr[k].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, goff[k], s0, 0));
+            rr[k].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, goff[k], s0 + cstride, 0));
+        }
+    };
+    fetch(0);
+    f32x2 acc[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[a][c][i] = f32x2{0.f, 0.f};
+    // this thread's 4 x 4 x 6 window: rows 2 lh + hy; their shift is 2 positions for (lh + (hy >> 1)) odd
+    const char* win0 = reinterpret_cast<const char*>(Xs) + v_slot(2 * ld, 2 * lh, 4 * lw) * 4;       // hy = 0, 1
+    const char* win2 = reinterpret_cast<const char*>(Xs) + v_slot(2 * ld, 2 * lh + 2, 4 * lw) * 4;   // hy = 2, 3
+    char* xs_c = reinterpret_cast<char*>(Xs);
+    for (int pair = 0; pair < npairs; ++pair) {
+        if (pair > 0) __syncthreads();                       // everyone has finished with the previous pair's tile
+#pragma unroll
+        for (int k = 0; k < VSLOTS; ++k) *reinterpret_cast<f32x2*>(xs_c + lslot[k]) = rr[k];
+        __syncthreads();
+        if (pair + 1 < npairs) fetch(pair + 1);              // in flight under the multiply-adds below
+        f32x2 wv[27];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) wv[t] = *reinterpret_cast<const f32x2*>(Ws + (pair * 27 + t) * 2);
+#pragma unroll
+        for (int dz = 0; dz < 4; ++dz)
+#pragma unroll
+            for (int hy = 0; hy < 4; ++hy) {
+                f32x2 row[6];
+                const float4* rp = reinterpret_cast<const float4*>((hy < 2 ? win0 : win2) + ((dz * VH_H + (hy & 1)) * VROW) * 8);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float4 v = rp[q];
+                    row[2 * q] = f32x2{v.x, v.y};
+                    row[2 * q + 1] = f32x2{v.z, v.w};
+                }
+#pragma unroll
+                for (int od = 0; od < 2; ++od) {
+                    const int kd = dz - od;
+                    if (kd < 0 || kd > 2) continue;
+#pragma unroll
+                    for (int oh = 0; oh < 2; ++oh) {
+                        const int kh = hy - oh;
+                        if (kh < 0 || kh > 2) continue;
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                acc[od][oh][i] = __builtin_elementwise_fma(row[i + kw], wv[(kd * 3 + kh) * 3 + kw], acc[od][oh][i]);
+                    }
+                }
+            }
+    }
+    float* yb = y + (size_t)b * DHW;
+    const int ow = w0 + 4 * lw;
+#pragma unroll
+    for (int od = 0; od < 2; ++od)
+#pragma unroll
+        for (int oh = 0; oh < 2; ++oh) {
+            const int z = d0 + 2 * ld + od, yy = h0 + 2 * lh + oh;
+            if (z >= D || yy >= H || ow >= W) continue;
+            float* dst = yb + ((size_t)z * H + yy) * W + ow;
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = acc[od][oh][i].x + acc[od][oh][i].y;
+            if (ow + 3 < W && (((size_t)z * H + yy) * W + ow) % 4 == 0 && (reinterpret_cast<size_t>(yb) & 15) == 0)
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            else
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ow + i < W) dst[i] = o[i];
+        }
+}
 
 // ------------------------------------------------------------------------------------------------ forward
 // Depth-marching: a workgroup owns an MTH x MTW output footprint and walks a range of input planes z.  Per plane:
@@ -350,6 +494,17 @@ inline long long c1_tiles(int B, int D, int H, int W) {
 extern "C" int ecm_conv3d_c1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, void* stream) {
     ECM_CHECK_ARG(x && w && y && B > 0 && Ci > 0 && D > 0 && H > 0 && W > 0);
     if (Ci > 32 || (long long)D * H * W * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;
+    static const bool valu = [] { const char* v = getenv("ECM_C1_VALU"); return !(v && v[0] == '0'); }();
+    if (valu && Ci % 2 == 0) {
+        const int td = (D + VT_D - 1) / VT_D, th = (H + VT_H - 1) / VT_H, tw = (W + VT_W - 1) / VT_W;
+        const long long nb = (long long)B * td * th * tw;
+        if (nb > 0x7fffffffLL) return ECM_EUNSUP;
+        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(conv3d_c1_fwd_v), V_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(conv3d_c1_fwd_v, dim3((unsigned)nb), dim3(256), V_LDS_BYTES, ecm_stream(stream), x, w, y, Ci, D, H, W, td, th,
+                           tw);
+        return ECM_LAUNCH_RESULT();
+    }
     const int tiles_h = (H + MTH - 1) / MTH, tiles_w = (W + MTW - 1) / MTW;
     // split the disparity axis only as far as needed to give the chip ~3 rounds of workgroups (each chunk re-reads 2 planes)
     const long long cols = (long long)B * tiles_h * tiles_w;

@@ -3,7 +3,7 @@
 (ECM_WINO_PERSIST=0: one block per workgroup; ECM_WINO_LATE_PCT: start offset of a CU's second workgroup)."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ecm_amd
 ops = ecm_amd.ops
 

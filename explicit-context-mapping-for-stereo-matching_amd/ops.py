@@ -518,8 +518,10 @@ def _deconv_fwd(x, packed, Co, out_dhw):
 # stream waits for the side stream once per backward pass, from an engine callback that runs when the pass has finished.
 # That is safe exactly when nothing reads a weight gradient DURING the pass: it is therefore OFF unless the training harness
 # that owns the gradients' consumers turns it on (dist.FlatBucketDDP does: it joins before it gathers) or ECM_WGRAD_OVERLAP=1
-# asks for it; non-leaf weights (nn.DataParallel replicas, whose gradients flow on through Broadcast.backward) and weights
-# with tensor hooks always stay on the main stream, and so does everything during graph capture.  ECM_WGRAD_OVERLAP=0: never.
+# asks for it; non-leaf weights (nn.DataParallel replicas, whose gradients flow on through Broadcast.backward), weights with
+# tensor hooks and weights that already HAVE a gradient (a layer used twice in one graph, accumulation over several passes:
+# AccumulateGrad then adds on the main stream at once) always stay on the main stream, and so does everything during graph
+# capture.  ECM_WGRAD_OVERLAP=0: never.
 _WGRAD_ENV = _os.environ.get("ECM_WGRAD_OVERLAP", "")
 WGRAD_OVERLAP = _WGRAD_ENV == "1"
 
@@ -533,7 +535,7 @@ def enable_wgrad_overlap(on=True):
     return prev
 
 
-_SIDE = {}                    # device index -> [side stream, join queued for the running backward pass]
+_SIDE = {}                    # device index -> [side stream, join queued for the running backward pass, weights seen since the join]
 
 
 def join_side_streams():
@@ -542,6 +544,7 @@ def join_side_streams():
         if st[0] is not None:
             torch.cuda.current_stream(dev).wait_stream(st[0])
         st[1] = False
+        st[2].clear()
 
 
 def _on_side(fn, w, *operands):
@@ -550,7 +553,16 @@ def _on_side(fn, w, *operands):
         return fn()
     st = _SIDE.get(dev.index)
     if st is None:
-        st = _SIDE[dev.index] = [torch.cuda.Stream(device=dev), False]
+        st = _SIDE[dev.index] = [torch.cuda.Stream(device=dev), False, set()]
+    if w.grad is not None or w.data_ptr() in st[2]:
+        # The weight already has a gradient (accumulation over several backward passes), or this pass has already produced one
+        # for it (a layer used twice in one graph -- the reference calls its encoder once per image): autograd will ADD the
+        # two on the main stream as soon as this node returns (AccumulateGrad, or the input buffer of the leaf's node), so
+        # both operands of that addition must be complete there.
+        join_side_streams()
+        st[2].add(w.data_ptr())
+        return fn()
+    st[2].add(w.data_ptr())
     side, main = st[0], torch.cuda.current_stream(dev)
     if side == main:
         return fn()

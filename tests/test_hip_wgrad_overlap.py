@@ -77,3 +77,29 @@ def test_non_leaf_and_hooked_weights_stay_on_the_main_stream(ecm):
         assert ref.shape == x.shape
     finally:
         ops.enable_wgrad_overlap(prev)
+
+
+def test_layer_used_twice_accumulates_correctly(ecm):
+    """The reference calls the shared encoder once per image (cmfsm.py:657-658): a weight then receives two gradients in one
+    pass and AccumulateGrad adds them on the main stream -- the second use must not leave either operand of that addition in
+    flight on the side stream."""
+    ops = ecm.ops
+    prev = ops.enable_wgrad_overlap(False)
+    try:
+        torch.manual_seed(5)
+        w = (torch.randn(32, 32, 3, 3, 3, device="cuda") * 0.05).requires_grad_()
+        xs = [torch.randn(2, 32, 24, 72, 120, device="cuda") for _ in range(3)]
+
+        def run():
+            w.grad = None
+            sum(ops.conv3d_k3(x, w, 1).square().sum() for x in xs).backward()
+            torch.cuda.synchronize()
+            return w.grad.clone()
+        ref = run()
+        ops.enable_wgrad_overlap(True)
+        if not ops.WGRAD_OVERLAP:
+            pytest.skip("ECM_WGRAD_OVERLAP=0 in the environment")
+        for _ in range(3):
+            assert torch.equal(run(), ref)
+    finally:
+        ops.enable_wgrad_overlap(prev)

@@ -347,15 +347,20 @@ class hourglass(nn.Module):
             HipConvTranspose3d(c2, inplanes, kernel_size=3, padding=1, output_padding=(1, 1, 1), stride=2, bias=False),
             HipGroupNorm(NUM_GROUPS, inplanes))
 
-    def forward(self, x, presqu, postsqu, residual=None):
-        """`residual` (extension): added to `out` inside the last GroupNorm kernel (cmfsm.py:687,690,693)."""
+    def forward(self, x, presqu, postsqu, residual=None, pre_uses=1):
+        """`residual` (extension): added to `out` inside the last GroupNorm kernel (cmfsm.py:687,690,693).
+        `pre_uses` (extension): how many times the CALLER will consume the returned `pre`; with more than one consumer in all
+        (conv3, the skip of conv5 when `presqu` is None, the caller's) their gradients are summed by one kernel (ops.fork)
+        instead of one autograd add each, and `pre` is returned as a tuple of `pre_uses` aliases."""
         out = _cbn(self.conv1[0], x, relu=True)                                   # :285
         pre = _cbn(self.conv2, out, skip=postsqu, relu=True)                      # :286-290
-        out = _cbn(self.conv3[0], pre, relu=True)                                 # :292
+        inner = 2 if presqu is None else 1
+        views = ops.fork(pre, inner + pre_uses) if pre_uses > 1 else (pre,) * (inner + pre_uses)
+        out = _cbn(self.conv3[0], views[0], relu=True)                            # :292
         out = _cbn(self.conv4[0], out, relu=True)                                 # :293
-        post = _cbn(self.conv5, out, skip=presqu if presqu is not None else pre, relu=True)   # :295-299
+        post = _cbn(self.conv5, out, skip=presqu if presqu is not None else views[1], relu=True)   # :295-299
         out = _cbn(self.conv6, post, skip=residual, relu=False)                   # :301
-        return out, pre, post
+        return out, (pre if pre_uses <= 1 else tuple(views[inner:])), post
 
 
 class similarity_measure1(nn.Module):
@@ -439,11 +444,12 @@ class cmfsm(nn.Module):
         # (fork), so that its data gradient absorbs the gradient arriving through the hourglass
         # cost0 has four consumers (first hourglass + three residual adds): one 4-ary gradient sum instead of three adds
         c_in, c_r1, c_r2, c_r3 = ops.fork(cost0, 4)
-        out1, pre1, post1 = self.dres2(c_in, None, None, residual=c_r1)                # :686-687
+        # pre1 has four consumers (two inside dres2, the skips of dres3 and dres4): one 4-ary gradient sum
+        out1, (pre1a, pre1b), post1 = self.dres2(c_in, None, None, residual=c_r1, pre_uses=2)   # :686-687
         h1, out1 = _cbn(self.classif1[0], out1, relu=True, fork=True)                  # :695
-        out2, pre2, post2 = self.dres3(out1, pre1, post1, residual=c_r2)               # :689-690
+        out2, pre2, post2 = self.dres3(out1, pre1a, post1, residual=c_r2)              # :689-690
         h2, out2 = _cbn(self.classif2[0], out2, relu=True, fork=True)                  # :724
-        out3, pre3, post3 = self.dres4(out2, pre1, post2, residual=c_r3)               # :692-693
+        out3, pre3, post3 = self.dres4(out2, pre1b, post2, residual=c_r3)              # :692-693
         h3 = _cbn(self.classif3[0], out3, relu=True)                                   # :747
         heads = [clf[2](h).squeeze(1) for clf, h in ((self.classif1, h1), (self.classif2, h2), (self.classif3, h3))]
         disp = ops.softargmin_heads(torch.stack(heads, 0))                             # :703-706,725-728,748-753

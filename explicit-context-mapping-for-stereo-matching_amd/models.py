@@ -292,8 +292,13 @@ class feature_extraction(nn.Module):
             return layer(x)
         return ops.phase_merge(layer(ops.phase_split(x, d)), d)
 
-    def forward(self, x):
+    def forward(self, x, head=None):
+        """`head` (extension): the caller only needs the first `head` samples of the full-resolution map (third result); their
+        gradient is then folded into the map's gradient in place (ops.fork_head) instead of through a zero-padded copy."""
         output_all = _seq_fused(self.firstconv, x)
+        output_head = None
+        if head is not None:
+            output_all, output_head = ops.fork_head(output_all, head)
         output_rt = self.layer1(_seq_fused(self.secondconv, output_all))
         output_raw = self.layer2(output_rt)
         if self._raw_is_layer3:                       # cmfsm_sub_16.py:205-207
@@ -306,7 +311,7 @@ class feature_extraction(nn.Module):
         pyramid = [bilinear_upsample(_seq_fused(getattr(self, f"branch{i}"), pooled[i - 1], start=1), size) for i in (4, 3, 2, 1)]
         last = self.lastconv_16 if self._raw_is_layer3 else self.lastconv
         feature = _seq_fused(last, torch.cat([output_raw, output_skip] + pyramid, 1))
-        return feature, output_rt, output_all
+        return feature, output_rt, (output_all if output_head is None else output_head)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -460,8 +465,8 @@ class cmfsm(nn.Module):
         # cmfsm.py:657-658 runs the shared encoder twice; both images go through it as ONE batch here (GroupNorm has no
         # cross-sample statistics, so the result is identical) -- half the launches, better-filled small layers.
         B = left.shape[0]
-        lr, _, hr = self.feature_extraction(torch.cat([left, right], 0))
-        return self.hot_path(lr[:B], hr[:B], lr[B:])
+        lr, _, hr = self.feature_extraction(torch.cat([left, right], 0), head=B)      # hr: the left images' map only
+        return self.hot_path(lr[:B], hr, lr[B:])
 
 
 class similarity_measure2(nn.Module):

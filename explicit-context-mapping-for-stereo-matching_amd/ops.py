@@ -487,6 +487,37 @@ class Fork(torch.autograd.Function):
         return gs[0], None
 
 
+class ForkHead(torch.autograd.Function):
+    """x -> (alias of x, x[:n]): one consumer of the whole batch and one of its first n samples (the encoder's full-resolution
+    map: the next encoder layer takes both images, the ECM weights only the left ones, cmfsm.py:657-664).  Autograd's own
+    route for that is a zero-filled full-size tensor, a copy of the slice gradient into it and a full-size add (2.8 GB of
+    traffic at batch 4); here the slice gradient is added INTO the first n samples of the full gradient, which this node
+    owns (it is the fresh output of the consuming layer's data-gradient kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x[:n]
+
+    @staticmethod
+    def backward(ctx, g_full, g_head):
+        if g_head is None:
+            return g_full, None
+        if g_full is None:
+            raise RuntimeError("ForkHead: the full-batch consumer produced no gradient")   # not a configuration of this model
+        g_full = _c(g_full)
+        g_full[:ctx.n].add_(g_head)
+        return g_full, None
+
+
+def fork_head(x, n):
+    """(alias of x, x[:n]) with the slice's gradient folded into the full gradient in place (see ForkHead)."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x[:n]
+    return ForkHead.apply(x, int(n))
+
+
 def fork(x, n):
     """n aliases of x for n consumers whose gradients are then summed by one kernel (see Fork)."""
     if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):

@@ -507,6 +507,8 @@ class ForkHead(torch.autograd.Function):
         if g_full is None:
             raise RuntimeError("ForkHead: the full-batch consumer produced no gradient")   # not a configuration of this model
         g_full = _c(g_full)
+        if g_full._is_view():                                # someone else's memory shows through it: do not write into that
+            g_full = g_full.clone()
         g_full[:ctx.n].add_(g_head)
         return g_full, None
 
@@ -571,7 +573,7 @@ _SIDE = {}                    # device index -> [side stream, join queued for th
 
 def join_side_streams():
     """Make the current stream wait for every weight gradient launched so far (a no-op when there is none)."""
-    for dev, st in _SIDE.items():
+    for dev, st in list(_SIDE.items()):                      # (a second device's autograd thread may add its entry meanwhile)
         if st[0] is not None:
             torch.cuda.current_stream(dev).wait_stream(st[0])
         st[1] = False

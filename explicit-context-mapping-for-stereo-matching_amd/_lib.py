@@ -42,6 +42,7 @@ PROTOTYPES = {
     "ecm_conv3d_k3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_conv_wino_packed_floats": (_LL, [_I, _I, _I]),
     "ecm_conv_wino_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ecm_conv_wino_pack_weight2": (_I, [_P, _P, _I, _I, _I, _P]),
     "ecm_conv_wino_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_conv_wino_fwd_add": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_sum_n": (_I, [_P, _P, _P, _P, _P, _LL, _P]),

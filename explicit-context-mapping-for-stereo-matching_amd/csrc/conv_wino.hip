@@ -412,9 +412,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
 
 // w [Co][Ci][KD][3][3] (or, flip_transpose: the data-gradient operator w'[ci][co][flipped taps]) -> U = G g G^T,
 // packed [co group][chunk][xi][kd][cc][32]
+// `both`: one launch produces the forward layout (n elements) followed by the data-gradient layout (n2 elements, nchunks2
+// chunks) -- a training step needs both and would otherwise pay two dependent 5 us launches per layer
 __global__ void pack_wino_weight(const float* __restrict__ w, float* __restrict__ packed, int Co, int Ci, int KD, int CIC,
-                                 int nchunks, int flip_transpose, long long n) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                                 int nchunks, int flip_transpose, long long n, int both = 0, int nchunks2 = 0, long long n2 = 0) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (both) {
+        if (idx >= n + n2) return;
+        if (idx >= n) { idx -= n; packed += n; flip_transpose = 1; nchunks = nchunks2; n = n2; }
+        else flip_transpose = 0;
+    }
     if (idx >= n) return;
     const int Kin = flip_transpose ? Co : Ci, Kout = flip_transpose ? Ci : Co;
     const int o = (int)(idx % 32);
@@ -484,6 +491,15 @@ extern "C" int ecm_conv_wino_pack_weight(const float* w, float* packed, int Co, 
     const long long n = ecm_conv_wino_packed_floats(Kin, Kout, kd);
     hipLaunchKernelGGL(pack_wino_weight, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ecm_stream(stream), w, packed, Co, Ci, kd,
                        cic, nchunks, flip_transpose, n);
+    return ECM_LAUNCH_RESULT();
+}
+
+extern "C" int ecm_conv_wino_pack_weight2(const float* w, float* packed, int Co, int Ci, int kd, void* stream) {
+    ECM_CHECK_ARG(w && packed && Co > 0 && Ci > 0 && (kd == 1 || kd == 3));
+    const int cic = kd == 3 ? WINO_CIC3 : WINO_CIC2;
+    const long long nf = ecm_conv_wino_packed_floats(Ci, Co, kd), nb = ecm_conv_wino_packed_floats(Co, Ci, kd);
+    hipLaunchKernelGGL(pack_wino_weight, dim3((unsigned)((nf + nb + 255) / 256)), dim3(256), 0, ecm_stream(stream), w, packed, Co, Ci,
+                       kd, cic, (Ci + cic - 1) / cic, 0, nf, 1, (Co + cic - 1) / cic, nb);
     return ECM_LAUNCH_RESULT();
 }
 

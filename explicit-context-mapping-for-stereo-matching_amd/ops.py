@@ -430,6 +430,35 @@ def _wino_pack(w, kd, flip_transpose):
     return _cached_pack(w, ("wT" if flip_transpose else "w") + str(kd), build)
 
 
+def _wino_pack_both(w, kd):
+    """(forward layout, data-gradient layout) from ONE launch: what a training step needs of a layer -- the second one is kept on
+    the autograd context for the backward of the same step (`_wino_pack_b`), which otherwise packs it in a dependent 5 us launch
+    right in front of the data-gradient kernel (67 such launches per step)."""
+    Co, Ci = w.shape[:2]
+    nf = _lib.query("ecm_conv_wino_packed_floats", Ci, Co, kd)
+    nb = _lib.query("ecm_conv_wino_packed_floats", Co, Ci, kd)
+    packed = torch.empty(nf + nb, device=w.device, dtype=w.dtype)
+    _lib.call("ecm_conv_wino_pack_weight2", _p(w), _p(packed), Co, Ci, kd, _stream())
+    return packed[:nf], (packed[nf:], w._version, w.data_ptr())
+
+
+def _wino_pack_fwd(ctx, x, w, kd):
+    """Forward layout of w; in a pass that will need the data gradient, also the backward layout (stored on ctx)."""
+    ctx.packed_b = None
+    if torch.is_grad_enabled() and x.requires_grad and not _FROZEN_DEPTH and not torch.cuda.is_current_stream_capturing():
+        pf, ctx.packed_b = _wino_pack_both(w, kd)
+        return pf
+    return _wino_pack(w, kd, False)
+
+
+def _wino_pack_b(ctx, w, kd):
+    """Data-gradient layout: the one packed in forward if the weight has not been written since, else a fresh one."""
+    pb = getattr(ctx, "packed_b", None)
+    if pb is not None and pb[1] == w._version and pb[2] == w.data_ptr():
+        return pb[0]
+    return _wino_pack(w, kd, True)
+
+
 def _wino_run(x, packed, Co, kd, addend=None):
     """x: [B,Ci,D,H,W] (kd 3; or kd 1 on D independent planes) or [B,Ci,H,W] (kd 1) -> same spatial shape with Co channels."""
     B, Ci = x.shape[:2]
@@ -677,7 +706,7 @@ class Conv3dK3(torch.autograd.Function):
             y = torch.empty(B, 1, D, H, W, device=x.device, dtype=x.dtype)
             _lib.call("ecm_conv3d_c1_fwd", _p(x), _p(w), _p(y), B, Ci, D, H, W, _stream())
         elif stride == 1 and _wino_ok(x):
-            y = _wino_run(x, _wino_pack(w, 3, False), w.shape[0], 3)
+            y = _wino_run(x, _wino_pack_fwd(ctx, x, w, 3), w.shape[0], 3)
         else:
             y = _conv_fwd(x, _pack_conv(w), w.shape[0], stride)
         ctx.save_for_backward(x, w)
@@ -704,7 +733,7 @@ class Conv3dK3(torch.autograd.Function):
 
         def dfn():
             if ctx.stride == 1 and _wino_ok(x) and not _is_c1(w, ctx.stride):
-                return _wino_run(gy, _wino_pack(w, 3, True), Ci, 3, addend=gskip)
+                return _wino_run(gy, _wino_pack_b(ctx, w, 3), Ci, 3, addend=gskip)
             if _is_c1(w, ctx.stride):
                 g = torch.empty(x.shape, device=x.device, dtype=x.dtype)
                 _lib.call("ecm_conv3d_c1_dgrad", _p(gy), _p(w), _p(g), x.shape[0], Ci, x.shape[2], x.shape[3], x.shape[4],
@@ -839,7 +868,7 @@ class Conv2dG(torch.autograd.Function):
         ctx.wino_f, ctx.wino_b = _wino_ok(x) and same and Ci >= WINO2D_MIN_CI, _wino_ok(x) and same and Co >= WINO2D_MIN_CI
         ctx.wino_same = same
         if ctx.wino_f:
-            y = _wino_run(x, _wino_pack(_c(w), 1, False), Co, 1)
+            y = _wino_run(x, _wino_pack_fwd(ctx, x, _c(w), 1), Co, 1)
         else:
             y = _conv2d_run(x, _pack2d(w, False), Co, kh, kw, stride, dil, pad_top, pad_left, Ho, Wo)
         ctx.save_for_backward(x, w)
@@ -870,7 +899,7 @@ class Conv2dG(torch.autograd.Function):
 
         def dfn():
             if ctx.wino_b:
-                return _wino_run(gy, _wino_pack(_c(w), 1, True), Ci, 1, addend=gskip)
+                return _wino_run(gy, _wino_pack_b(ctx, _c(w), 1), Ci, 1, addend=gskip)
             if stride == 1:
                 # gx[i] = sum_k w[k] gy[i + pad - k*dil]: the conv of gy with the flipped kernel, padding (K-1)*dil - pad
                 g = _conv2d_run(gy, _pack2d(w, True), Ci, kh, kw, 1, dil, (kh - 1) * dil - pad_top, (kw - 1) * dil - pad_left,
@@ -942,7 +971,7 @@ class Conv2dPlanes(torch.autograd.Function):
         x, w = _c(x), _c(w)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, w)
-        return _fork_out(_wino_run(x, _wino_pack(w, 1, False), w.shape[0], 1), x, fork)
+        return _fork_out(_wino_run(x, _wino_pack_fwd(ctx, x, w, 1), w.shape[0], 1), x, fork)
 
     @staticmethod
     def backward(ctx, gy, gskip=None):
@@ -951,7 +980,7 @@ class Conv2dPlanes(torch.autograd.Function):
             return gskip, None, None
         gy = _c(gy)
         gx, gw = _launch_pair((lambda: _wino_wgrad(x, gy, w.shape[0], w.shape[1], 1, w)) if ctx.needs_input_grad[1] else None,
-                              (lambda: _wino_run(gy, _wino_pack(w, 1, True), w.shape[1], 1, addend=gskip)) if ctx.needs_input_grad[0] else None)
+                              (lambda: _wino_run(gy, _wino_pack_b(ctx, w, 1), w.shape[1], 1, addend=gskip)) if ctx.needs_input_grad[0] else None)
         return gx, gw, None
 
 

@@ -140,6 +140,9 @@ int ecm_conv3d_k3_fwd(const float* x, const float* wpacked, float* y,
  * with the swapped counts). */
 long long ecm_conv_wino_packed_floats(int Ci, int Co, int kd);
 int ecm_conv_wino_pack_weight(const float* w, float* packed, int Co, int Ci, int kd, int flip_transpose, void* stream);
+/* Both layouts in one launch: packed[0 .. packed_floats(Ci,Co,kd)) = the forward layout, followed by the data-gradient layout
+ * (packed_floats(Co,Ci,kd) floats) -- what a training step needs of every layer (forward now, backward later). */
+int ecm_conv_wino_pack_weight2(const float* w, float* packed, int Co, int Ci, int kd, void* stream);
 int ecm_conv_wino_fwd(const float* x, const float* upacked, float* y, int B, int Ci, int Co, int D, int H, int W, int kd,
                       void* stream);
 /* out = ((a + b) + c) + d elementwise over n floats, c and d optional (NULL): the gradient accumulation of a tensor with

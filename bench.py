@@ -4,8 +4,9 @@
 ms per cost volume, on N MI355X of one node.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          # starts its own N ranks (the parent never touches a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # ... or runs as one rank of an external launcher
 
 Prints ONE JSON line on rank 0.  Extra objects: `roofline` (dominant kernel, live HIP-event timing), `roofline_costvol`
 (the HBM-bound cost-volume build), `roofline_worst` (the kernels furthest below their roofline, live-timed in the same
@@ -157,8 +158,99 @@ def _timed(fn, steps, warmup, sync):
     return (time.perf_counter() - t0) / steps
 
 
+def launch_ranks(args):
+    """`bench.py --gpus N` without a launcher's environment: this process becomes the PARENT of N fresh rank processes
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would, rendezvous on 127.0.0.1), relays rank 0's
+    JSON line and exits with the worst child code.  The parent makes no HIP call at all (nothing here touches torch.cuda) and
+    no process is ever replaced by another: every rank is a child started from scratch.  If one rank dies the others would
+    wait in a collective for ever, so they are ended (by PID) once any rank has failed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this host driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))     # rank 0 prints the line
+    worst, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        rcs = [p.poll() for p in procs]
+        bad = [rc for rc in rcs if rc not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at = time.time()
+            print(f"[bench] a rank exited with {bad[0]}: ending the other ranks", file=sys.stderr, flush=True)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        if failed_at is not None and time.time() - failed_at > 20:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for p in procs:
+        rc = p.wait()
+        worst = worst or (rc if rc > 0 else (128 - rc if rc < 0 else 0))
+    sys.exit(worst)
+
+
+def _family(name, a):
+    """Kernel family of one C-ABI launch (entry point + its integer arguments): the rows of DESIGN section 6's table."""
+    if name.startswith("ecm_conv_wino_fwd"):                # (B,Ci,Co,D,H,W,kd)
+        return "winograd_conv_3d" if a[6] == 3 else "winograd_conv_2d"
+    if name == "ecm_conv_wino_wgrad":                       # (nbytes?,B,Ci,Co,D,H,W,kd): kd is the last int
+        return "winograd_wgrad_3d" if a[-1] == 3 else "winograd_wgrad_2d"
+    if name in ("ecm_conv3d_k3_fwd", "ecm_conv3d_k3_wgrad") and a[6] == 1:      # (B,Ci,Co,D,H,W,stride): ECM_WINOGRAD=0 only
+        return "direct_conv_3d_stride1"
+    if name in ("ecm_conv3d_k3_fwd", "ecm_conv3d_k3_wgrad", "ecm_deconv3d_k3s2_fwd"):
+        return "stride2_conv_deconv_wgrad_3d"
+    if name.startswith("ecm_gn3d"):
+        return "groupnorm"
+    if name.startswith("ecm_conv3d_c1"):
+        return "classifier_32to1"
+    if name.startswith("ecm_weights9") or name.startswith("ecm_context_weights"):
+        return "ecm_weights"
+    if name.startswith("ecm_conv2d") or name.startswith("ecm_deconv2d") or name == "ecm_zero_insert2d":
+        return "conv2d_direct_family"
+    if "pack_weight" in name or name.startswith("ecm_costvol_class_weights"):
+        return "weight_packing"
+    if name.startswith("ecm_costvol"):
+        return "cost_volume_assemble"
+    if name in ("ecm_softargmin_heads_fwd", "ecm_softargmin_heads_bwd", "ecm_aggregate9_fwd", "ecm_aggregate9_bwd",
+                "ecm_stereo_loss_fwd", "ecm_stereo_loss_bwd"):
+        return "heads_and_loss"
+    if name == "ecm_sum_n":
+        return "gradient_sums"
+    return "other_hip"
+
+
+def step_breakdown(timers, n_steps):
+    """Per-family device time of ONE step in ms, from the second pass's per-launch HIP events (every C-ABI launch of the
+    step; what runs on ATen -- pooling, cat, Adam, autograd's own adds -- is not in it and shows up as the difference to
+    ms_per_step)."""
+    fam = {}
+    launches = 0
+    for name, evs in timers.items():
+        for s_, e_, a in evs:
+            k = _family(name, a)
+            fam[k] = fam.get(k, 0.0) + s_.elapsed_time(e_)
+            launches += 1
+    out = {k: v / n_steps for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}
+    out["_sum_hip_launches"] = sum(fam.values()) / n_steps
+    out["_launches_per_step"] = launches / n_steps
+    out["_source"] = (f"HIP events around every C-ABI launch, second pass of {n_steps} steps with the weight gradients on the "
+                      "main stream (no overlap), so the sum exceeds the timed step where the side stream hides part of it")
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)              # never returns
     import ecm_amd
     from importlib import import_module
     ecm_dist = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
@@ -172,8 +264,12 @@ def main():
     ndev = torch.cuda.device_count()
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)
     torch.cuda.set_device(local)
+    if backend == "nccl" and int(os.environ.get("WORLD_SIZE", "1")) > ndev:
+        raise SystemExit(f"bench.py: {os.environ['WORLD_SIZE']} ranks over RCCL need as many GPUs, this box has {ndev} "
+                         "(ECM_DIST_BACKEND=gloo rehearses the N>1 path with ranks sharing devices)")
     rank, world, _ = ecm_dist.init_from_env(backend, device=local)
     assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    devices = min(world, ndev)          # distinct GPUs in use: ranks share devices round-robin only under gloo
     if world > ndev:
         # several PROCESSES on one device: the one-pass GroupNorm kernels wait across workgroups, which is only safe to
         # rely on when at most a few launches share the device -- take the two-stage kernels (no inter-workgroup waits)
@@ -258,10 +354,13 @@ def main():
     overlap_was = ops.enable_wgrad_overlap(False)
     for name in TIMED:
         lib.enable_timer(name)
-    for _ in range(min(args.steps, 5)):                    # every rank: the training step holds a collective
+    lib.enable_all_timers()                                # ... and every other entry point, for step_breakdown_ms
+    n_pass2 = min(args.steps, 5)
+    for _ in range(n_pass2):                               # every rank: the training step holds a collective
         step()
     torch.cuda.synchronize()
     timers = lib.disable_timers()
+    breakdown = step_breakdown(timers, n_pass2)
     ops.enable_wgrad_overlap(overlap_was)
     ops.check_async_errors()                               # a GroupNorm cluster time-out during the timed steps is fatal
     last = step()                                          # outside the timed region: the result must be finite
@@ -435,6 +534,23 @@ def main():
             worst["conv3d_wgrad_stride2"] = {"kernel": "conv3d_wgrad_mfma (stride-2 layers: hourglass conv1/conv3 and the deconvs' weight gradients)",
                                              "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                              "frac": tf / PEAK_F32_MFMA_TFLOPS, "launches_timed": len(wg2), "avg_launch_ms": tot / len(wg2)}
+        w2 = [(s, e, a) for n_ in ("ecm_conv_wino_fwd", "ecm_conv_wino_fwd_add") for (s, e, a) in timers.get(n_, []) if a[6] == 1]
+        if w2:
+            # 2-D Winograd F(2x2,3x3) (encoder + class convolutions, forward and data gradient; D = independent planes):
+            # direct count 2*9*Ci*Co per output pixel, of which the kernel executes 16/36 on the matrix cores
+            tot = sum(s.elapsed_time(e) for s, e, _ in w2)
+            flop = sum(2.0 * 9 * a[1] * a[2] * a[0] * a[3] * a[4] * a[5] for _, _, a in w2)
+            tf = flop / (tot * 1e-3) / 1e12
+            big = [(s, e, a) for (s, e, a) in w2 if a[1] == 32 and a[2] == 32 and a[4] * a[5] == H * W]
+            bt = sum(s.elapsed_time(e) for s, e, _ in big)
+            bf = sum(2.0 * 9 * 32 * 32 * a[0] * a[3] * a[4] * a[5] for _, _, a in big)
+            worst["conv_wino_2d"] = {"kernel": "conv_wino_mfma<1,1,2,4> / <1,2,..> (2-D Winograd: encoder and class convolutions, fwd + dgrad)",
+                                     "bound": "mfma", "achieved": tf * 16.0 / 36.0, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": tf * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS, "executed_over_algorithmic": 16.0 / 36.0,
+                                     "algorithmic_equiv_TFLOPs": tf, "launches_timed": len(w2), "avg_launch_ms": tot / len(w2),
+                                     "ms_per_step": tot / n_pass2,
+                                     "of_which_32to32_fullres": ({"frac": bf / (bt * 1e-3) / 1e12 * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS,
+                                                                  "avg_launch_ms": bt / len(big), "launches_timed": len(big)} if big else None)}
         c1 = [(s, e, a) for (s, e, a) in timers.get("ecm_conv3d_c1_fwd", [])]                     # (B,Ci,D,H,W)
         if c1:
             tot = sum(s.elapsed_time(e) for s, e, _ in c1)
@@ -486,7 +602,7 @@ def main():
         # roofline.traffic: HBM bytes per launch from rocprofv3 PMC passes of THIS round (profiles/r02_pmc_traffic.json, written
         # by tools/pmc_traffic.py with the calibration of tools/micro/fetch_calib.hip applied); null until that file exists --
         # round 1's figure used an uncalibrated FETCH_SIZE for 4-byte-per-lane buffer loads and read below the algorithmic bytes.
-        traffic_cv = traffic_conv = None
+        traffic_cv = traffic_conv = traffic_source = None
         traffic_note = "no calibrated PMC pass on file (profiles/r0N_pmc_traffic.json)"
         try:
             import glob
@@ -498,12 +614,14 @@ def main():
                                   else "conv3d_k3_mfma_32to32_B4"]["hbm_bytes_per_launch"]
                 traffic_cv = pm["costvol_fwd_v4_B4"]["hbm_bytes_per_launch"]
                 traffic_note = pm.get("note", "rocprofv3 PMC, calibrated") + f" [{os.path.basename(pmc_file)}]"
+                traffic_source = "profiles/" + os.path.basename(pmc_file) + " (a committed rocprofv3 --pmc run, NOT measured in this run)"
         except (OSError, KeyError, ValueError, IndexError):
             pass
         out = {
             "metric": "stereo-pairs/sec (cmfsm train step fwd+bwd+Adam)" if args.mode == "train"
                       else "stereo-pairs/sec (cmfsm eval forward)",
-            "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": pairs / dt, "unit": "pairs/s", "n_gpus": devices, "ranks": world, "devices": devices,
+            "backend": backend if world > 1 else "none (single process)", "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{shape_name} D={D} batch={B}/GPU "
@@ -523,7 +641,7 @@ def main():
                                                "note": "direct-convolution FLOP count 2*27*Ci*Co*voxels / time (SURVEY 8d); not a "
                                                        "roofline fraction for a Winograd kernel"},
                          "executed_over_algorithmic": executed,
-                         "traffic": traffic_conv, "traffic_note": traffic_note,
+                         "traffic": traffic_conv, "traffic_source": traffic_source, "traffic_note": traffic_note,
                          "launches_timed": len(sel), "avg_launch_ms": conv_ms,
                          "timing": "HIP events per launch on the launch stream, second pass after the timed steps with the weight "
                                    "gradients back on the main stream (in the timed steps they overlap the rest of backward on a "
@@ -533,10 +651,15 @@ def main():
                                              "avg_launch_ms": main_ms, "launches_timed": len(main_l)}},
             "roofline_costvol": {"kernel": "costvol_fwd_v4", "bound": "hbm", "achieved": cv_gbs, "peak": PEAK_HBM_GBS,
                                  "unit": "GB/s", "frac": cv_gbs / PEAK_HBM_GBS, "traffic": traffic_cv,
+                                 "traffic_source": traffic_source,
                                  "launches_timed": len(cv), "avg_launch_ms": cv_ms},
             "roofline_worst": worst,
+            "step_breakdown_ms": breakdown,
         }
         if explicit is not None:
+            # the reading with north_star's cost-volume kernel ON the step's path, as top-level scalars
+            out["explicit_ms_per_step"] = explicit["ms_per_step"]
+            out["explicit_pairs_per_s"] = explicit["value"]
             out["explicit_cost_volume"] = explicit
         if configs:
             out["configs"] = configs

@@ -120,15 +120,24 @@ def missing_symbols():
 # Optional per-launch timing (bench.py's roofline leg): name -> list of (start_event, end_event, int_args).
 # Events are recorded on torch's current stream, which is the stream every kernel is launched on.
 _timers = {}
+_time_all = False
 
 
 def enable_timer(name: str):
     _timers[name] = []
 
 
+def enable_all_timers():
+    """Time EVERY int-returning entry point from now on (bench.py's per-family step breakdown)."""
+    global _time_all
+    _time_all = True
+
+
 def disable_timers():
+    global _time_all
     out = dict(_timers)
     _timers.clear()
+    _time_all = False
     return out
 
 
@@ -139,6 +148,8 @@ def call(name: str, *args):
     if fn is None:
         raise RuntimeError(f"libecm_hip.so does not export {name}")
     rec = _timers.get(name)
+    if rec is None and _time_all:
+        rec = _timers[name] = []
     if rec is not None:
         import torch
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -62,7 +62,10 @@ class FlatBucketDDP:
     without dividing.  Without it, gradients are averaged (equal-count shards)."""
 
     def __init__(self, module: torch.nn.Module, world: int | None = None, late_module: str | None = "feature_extraction",
-                 overlap_wgrad: bool = True):
+                 overlap_wgrad: bool = True, always_reduce: bool = False):
+        """`always_reduce`: run the collectives (broadcast, count and bucket all-reduces, the side-stream slice) even in a
+        process group of ONE rank -- every step then goes through the communicator exactly as at N > 1 (a 1-GPU box can so
+        exercise RCCL: tests/test_dist_gpu.py); needs an initialised process group."""
         self.module = module
         if overlap_wgrad and next(module.parameters()).is_cuda:
             # this class owns every reader of the weight gradients (the bucket gather; the optimizer behind
@@ -70,6 +73,7 @@ class FlatBucketDDP:
             from . import ops
             ops.enable_wgrad_overlap(True)
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self._collective = self.world > 1 or (always_reduce and dist.is_initialized())
         named = [(k, p) for k, p in module.named_parameters() if p.requires_grad]
         late = getattr(module, late_module, None) if late_module else None
         late_ids = {id(p) for p in late.parameters()} if late is not None else set()
@@ -96,10 +100,10 @@ class FlatBucketDDP:
         self._fired = 0
         self._expected = None
         self._side = torch.cuda.Stream(device=ref.device) if ref.is_cuda else None
-        self.overlap = self.world > 1 and late is not None and 0 < self.n_late < len(self.params)
+        self.overlap = self._collective and late is not None and 0 < self.n_late < len(self.params)
         if self.overlap:
             late.register_forward_hook(self._watch_late_outputs)
-        if self.world > 1:
+        if self._collective:
             self.broadcast_parameters()
 
     def broadcast_parameters(self, src: int = 0):
@@ -127,7 +131,7 @@ class FlatBucketDDP:
         over the GLOBAL batch.  A rank with an empty mask contributes nothing, and a step whose mask is empty on EVERY rank
         has loss 0 with zero (not NaN) gradients.  Contract: every rank calls this in every step it calls
         allreduce_gradients() in (it holds a collective, and switches that step's reduction from average to sum)."""
-        if self.world == 1:
+        if not self._collective:
             return loss
         count = count.detach().to(loss.dtype)
         total = count.clone()
@@ -194,7 +198,7 @@ class FlatBucketDDP:
         and leave every .grad pointing at its slice of the bucket for the optimizer."""
         early_done = self._early_work is not None
         self._gather(0, self.n_late if early_done else len(self.params))      # (joins the weight-gradient stream first)
-        if self.world > 1:
+        if self._collective:
             if early_done:
                 if self.n_late:
                     dist.all_reduce(self.flat[:self.early_off], op=dist.ReduceOp.SUM)

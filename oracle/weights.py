@@ -65,3 +65,24 @@ def eval_harness_inputs():
     frame = np.concatenate([np.random.RandomState(9).randint(0, 256, size=(h, w, 6)).astype(np.float32),
                             (np.random.RandomState(10).rand(h, w, 1) * 200.0).astype(np.float32)], 2)
     return dict(sf_disparity=disp, sf_output3=out3, kitti_output3=o3k, kitti_hw=(h, w), kitti_frame=frame)
+
+
+def fullframe_frame(kind: str):
+    """Raw [H,W,7] float32 frame (left RGB, right RGB as uint8-valued floats, disparity) of the full-frame fixtures
+    (tests/golden/make_golden_fullframe.py and the tests that check them build the SAME frame from this function):
+    kind "sceneflow" = 540x960 (padded to 576x960 by the loader, Flying3d.py:66-72), "kitti" = 375x1242 (padded to
+    384x1248, KITTI.py:98-108).  8x8-blocky random colours + per-pixel noise, the right image = the left one shifted by a
+    row-dependent disparity (so the two maps are related), disparity channel = that shift."""
+    import numpy as np
+    H, W = {"sceneflow": (540, 960), "kitti": (375, 1242)}[kind]
+    rs = np.random.RandomState(zlib.crc32(("fullframe:" + kind).encode()) & 0x7FFFFFFF)
+    hb, wb = (H + 7) // 8, (W + 7) // 8
+    base = np.repeat(np.repeat(rs.randint(32, 224, size=(hb, wb, 3)), 8, 0), 8, 1)[:H, :W]
+    left = np.clip(base + rs.randint(-31, 32, size=(H, W, 3)), 0, 255).astype(np.float32)
+    disp_rows = (8 + 100 * (np.arange(H) / H)).astype(np.int64)                 # 8 .. 107 px, growing downwards
+    cols = np.arange(W)[None, :] + disp_rows[:, None]                           # right[x] = left[x + d]  (x_r = x_l - d)
+    right = left[np.arange(H)[:, None], np.clip(cols, 0, W - 1)]
+    right = np.clip(right + rs.randint(-4, 5, size=(H, W, 3)), 0, 255).astype(np.float32)
+    disp = np.broadcast_to(disp_rows[:, None].astype(np.float32), (H, W)).copy()
+    disp[rs.rand(H, W) < 0.05] = 0.0                                            # some invalid pixels (mask edges)
+    return np.concatenate([left, right, disp[..., None]], 2).astype(np.float32)

@@ -244,3 +244,20 @@ def test_empty_global_mask_and_accumulation_guard_two_ranks():
 def _params_in(names):
     byname = dict(_TwoStage().named_parameters())
     return [byname[k] for k in names]
+
+
+def test_bench_parent_ends_cleanly_when_the_ranks_fail():
+    """bench.py --gpus 2 on a box without GPUs: both ranks fail their `needs MI355X` assertion; the parent (which never
+    touches a GPU itself) must notice, not hang in a rendezvous, and exit non-zero."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check of the launcher's failure path")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs MI355X" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

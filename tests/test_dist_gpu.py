@@ -92,3 +92,90 @@ def test_two_ranks_real_model_gradients_equal_global_batch():
         # two batch-1 backward passes summed vs one batch-2 pass: fp32 summation order differs in the weight gradients
         torch.testing.assert_close(a, ref, rtol=2e-3, atol=2e-5 * scale)
     assert torch.equal(r0["grads"][0], r0["grads"][1])            # plain path == overlapped path (same inputs, same weights)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# RCCL itself: a process group of ONE rank over backend "nccl" on the MI355X -- loads librccl, builds a
+# communicator and runs every collective of the training step through it (parameter broadcast, the mask-count all-reduce,
+# the bucket all-reduce, and on the second step the overlapped path: the non-encoder slice reduced on a side stream under
+# the encoder's backward).  A sum over one rank is the identity, so the reduced bucket must equal the plain gradient bit
+# for bit.
+def _rccl_worker(rank, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from importlib import import_module
+    import ecm_amd as ecm
+    D = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    model = _model(ecm)
+    ddp = D.FlatBucketDDP(model, 1, late_module="feature_extraction", always_reduce=True)
+    assert ddp._collective and ddp.overlap
+    left, right, gt = (t[:1].cuda() for t in _inputs())
+    grads, early = [], []
+    for _ in range(2):
+        ddp.zero_grad()
+        loss, count = D.masked_smooth_l1_x3_with_count(model(left, right), gt, MAXD)
+        ddp.global_mean_loss(loss, count).backward()
+        early.append(ddp._early_work is not None)
+        ddp.allreduce_gradients()
+        torch.cuda.synchronize()
+        ecm.ops.check_async_errors()
+        grads.append(ddp.flat.detach().cpu().clone())
+    t = torch.ones(4, device="cuda")
+    dist.all_reduce(t)
+    dist.barrier(device_ids=[0])
+    with open("/proc/self/maps") as f:
+        rccl = sorted({line.split()[-1] for line in f if "librccl" in line})
+    order = {id(p): k for k, p in model.named_parameters()}
+    torch.save({"grads": grads, "early": early, "rccl": rccl, "backend": dist.get_backend(),
+                "order": [order[id(p)] for p in ddp.params], "ones": t.cpu()}, os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_world1_flat_bucket_allreduce():
+    from importlib import import_module
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    import ecm_amd as ecm
+    D = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
+    port = 35500 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_rccl_worker, args=(port, d), nprocs=1, join=True)
+        r = torch.load(os.path.join(d, "rccl.pt"))
+    assert r["backend"] == "nccl" and r["rccl"], f"librccl was not mapped by the worker: {r['rccl']}"
+    assert r["early"] == [False, True]                            # step 1 took the side-stream (overlapped) path
+    assert torch.equal(r["ones"], torch.ones(4))
+    model = _model(ecm)
+    left, right, gt = (t[:1].cuda() for t in _inputs())
+    loss, _ = D.masked_smooth_l1_x3_with_count(model(left, right), gt, MAXD)
+    loss.backward()
+    torch.cuda.synchronize()
+    byname = dict(model.named_parameters())
+    ref = torch.cat([byname[k].grad.flatten() for k in r["order"]]).cpu()
+    for g in r["grads"]:
+        assert torch.isfinite(g).all()
+        assert torch.equal(g, ref)                                # sum over one rank = identity, plain and overlapped path
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (as the driver invokes it): the parent starts two fresh ranks,
+    relays rank 0's JSON line and exits 0.  On the 1-GPU box the ranks share the device (gloo rendezvous), which the line
+    must say: ranks 2, devices 1."""
+    import json
+    import subprocess
+    env = dict(os.environ, ECM_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
+                        "--height", "256", "--width", "512", "--no-cpu-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    ndev = torch.cuda.device_count()
+    assert out["ranks"] == 2 and out["devices"] == min(2, ndev) and out["n_gpus"] == out["devices"] and out["backend"] == "gloo"
+    assert out["config"]["global_batch"] == 2 and out["value"] > 0 and out["scaling"] == "weak"

@@ -1,0 +1,125 @@
+"""BASELINE configs 1, 2 and 4 pinned to the REFERENCE at their own sizes.
+
+Fixtures g11 (tests/golden/make_golden_fullframe.py) hold the reference's cmfsm (cmfsm.py:655-774) evaluated in the build
+container on one SceneFlow-shaped frame padded to 576x960 (Flying3d.py:66-72) and one KITTI-shaped frame padded to 384x1248
+(KITTI.py:98-108), in fp32 and in fp64, sub-sampled: the three outputs, both low-resolution features, the nine ECM weight
+planes and the raw outputs of classif1..3.  Here the HIP path runs the whole chain on the same raw frame -- frame preparation
+(padding + normalisation), encoder, hot path -- and every stored tensor must sit as close to the fp64 truth as another fp32
+evaluation can: within K = 4 x the reference-fp32's own distance (max and mean) plus a small floor; the outputs additionally
+within max 2e-3 px / mean (1 + i) x 1e-4 px of fp64 (the tolerance of tests/test_hip_fp64_yardstick.py at 256x512).
+Then the batch-4 forward must equal the B = 1 runs sample by sample (quirk Q1's diagonal, at full size)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from oracle import ecm_oracle as O
+from oracle.weights import fullframe_frame, make_state_dict
+
+pytestmark = pytest.mark.gpu
+K = 4.0
+KINDS = {"sceneflow": (576, 960), "kitti": (384, 1248)}
+
+
+@pytest.fixture(scope="module")
+def ecm():
+    assert torch.cuda.is_available()
+    import ecm_amd
+    return ecm_amd
+
+
+@pytest.fixture(scope="module")
+def model(ecm, cmfsm_shapes):
+    m = ecm.get_model("cmfsm")
+    m.load_state_dict(make_state_dict(cmfsm_shapes))
+    return m.cuda().eval()
+
+
+def _prep(ecm, kind, frames):
+    """frames: float32 [B,H,W,7] on the device -> (left, right, disparity) padded + normalised by the HIP frame kernel."""
+    H, W = KINDS[kind]
+    if kind == "sceneflow":
+        B = frames.shape[0]
+        return ecm.ops.frame_prep(frames, [0] * B, [0] * B, H, W, split=540, tail=36)
+    return ecm.ops.frame_prep_kitti_eval(frames, H, W)
+
+
+def _run(ecm, model, left, right):
+    """The model's forward, stage by stage, so that the intermediate tensors of the fixture can be read."""
+    B = left.shape[0]
+    cap = {}
+    hooks = [getattr(model, f"classif{k}")[2].register_forward_hook(lambda m, i, o, k=k: cap.__setitem__(k, o.detach()))
+             for k in (1, 2, 3)]
+    with torch.no_grad():
+        lr, _, hr = model.feature_extraction(torch.cat([left, right], 0), head=B)
+        w9 = model.mapping_matrix.weights(lr[:B], hr)
+        preds = model.hot_path(lr[:B], hr, lr[B:])
+        whole = model(left, right)
+    for h in hooks:
+        h.remove()
+    for a, b in zip(preds, whole):
+        assert torch.equal(a, b)                                   # the staged run IS the forward
+    return dict(o1=preds[0], o2=preds[1], o3=preds[2], lr_l=lr[:B], lr_r=lr[B:], w9=w9, c1=cap[1], c2=cap[2], c3=cap[3])
+
+
+def _sub(k, t):
+    if k.startswith("o") or k.startswith("lr"):
+        return t[..., ::4, ::4]
+    if k == "w9":
+        return t[..., ::8, ::8]
+    return t[:, 0, ::2, ::4, ::4]
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_fullframe_vs_reference_fp64(ecm, model, kind):
+    H, W = KINDS[kind]
+    with np.load(os.path.join(GOLDEN, f"g11_fullframe_{kind}_{H}x{W}.npz")) as z:
+        z = {k: z[k] for k in z.files}
+    frame = fullframe_frame(kind)
+    left, right, _ = _prep(ecm, kind, torch.from_numpy(frame[None].copy()).cuda())
+    # the HIP frame preparation against the loader restatement the fixture's inputs were made with
+    want = O.flying3d_sample(frame, "test")[:2] if kind == "sceneflow" else O.kitti_eval_sample(frame)[:2]
+    for got, w_ in zip((left, right), want):
+        torch.testing.assert_close(got[0].cpu(), w_, rtol=0, atol=1e-6)
+    got = _run(ecm, model, left, right)
+    ecm.ops.check_async_errors()
+    report = []
+    for k, t in got.items():
+        g = _sub(k, t).double().cpu().numpy()
+        t64, t32 = z[k + "_64"], z[k + "_32"]
+        assert g.shape == t64.shape, (k, g.shape, t64.shape)
+        e = np.abs(g - t64)
+        e32max, e32mean = float(z["e32max_" + k]), float(z["e32mean_" + k])
+        scale = float(np.abs(t64).max())
+        report.append(f"{k}: hip-fp64 max {e.max():.2e} mean {e.mean():.2e} | ref32-fp64 max {e32max:.2e} mean {e32mean:.2e}")
+        assert e.max() <= K * e32max + 1e-5 * scale, f"{kind} {k}: max |hip - fp64| {e.max():.3e}, reference fp32 {e32max:.3e}\n" + "\n".join(report)
+        assert e.mean() <= K * e32mean + 1e-6 * scale, f"{kind} {k}: mean |hip - fp64| {e.mean():.3e}, reference fp32 {e32mean:.3e}"
+        # and against the reference's own fp32 output, at the stated end-to-end / per-stage tolerance
+        d32 = np.abs(g - t32.astype(np.float64))
+        if k.startswith("o"):
+            i = int(k[1]) - 1
+            assert e.max() <= 2e-3 and e.mean() <= (1 + i) * 1e-4, f"{kind} {k}: {e.max():.3e} / {e.mean():.3e} px from fp64"
+            assert d32.max() <= 2e-2 and d32.mean() <= 1e-3
+        else:
+            assert d32.max() <= 1e-4 * scale + K * e32max
+    print(f"\n[{kind}] " + "\n  ".join(report))
+
+
+@pytest.mark.parametrize("kind,B", [("sceneflow", 4), ("kitti", 2)])
+def test_fullframe_batch_equals_single_runs(ecm, model, kind, B):
+    """cfg 2 / cfg 3 run 4 pairs per GPU: sample b of the batched forward must be the B = 1 forward of pair b (the
+    reference's [B,B,H,W] broadcast, quirk Q1, has exactly that on its diagonal)."""
+    frame = fullframe_frame(kind)
+    frames = np.stack([np.roll(frame, 37 * b, axis=1) if b else frame for b in range(B)])
+    left, right, _ = _prep(ecm, kind, torch.from_numpy(frames).cuda())
+    with torch.no_grad():
+        batched = [p.clone() for p in model(left, right)]
+        for b in range(B):
+            single = model(left[b:b + 1], right[b:b + 1])
+            for i, (pb, ps) in enumerate(zip(batched, single)):
+                assert pb.shape == (B, 1) + KINDS[kind]
+                d = (pb[b] - ps[0]).abs()
+                assert float(d.max()) <= 2e-4, f"{kind} sample {b} head {i + 1}: batched vs single differ by {float(d.max()):.3e} px"
+    ecm.ops.check_async_errors()

@@ -246,3 +246,22 @@ def test_kitti_loss_and_metrics_golden():
     torch.testing.assert_close(epe, g["epe"], rtol=0, atol=0)
     torch.testing.assert_close(err3, g["loss_3"], rtol=0, atol=0)
     assert 5.0 < float(err3) < 60.0                                  # the fixture exercises both branches of the 3-px test
+
+
+@pytest.mark.parametrize("kind,H,W", [("kitti", 384, 1248)])
+def test_g11_fullframe_oracle_vs_reference(cmfsm_sd, kind, H, W):
+    """The oracle at a BASELINE size against the reference's own full-frame run (fixture g11, make_golden_fullframe.py):
+    KITTI 384x1248 here (~5 s on 8 threads); the 576x960 frame is checked through the HIP path on the GPU box."""
+    import numpy as np
+    from oracle.weights import fullframe_frame
+    with np.load(os.path.join(GOLDEN, f"g11_fullframe_{kind}_{H}x{W}.npz")) as z:
+        want = [z[f"o{i}_32"] for i in (1, 2, 3)]
+        w64 = [z[f"o{i}_64"] for i in (1, 2, 3)]
+    left, right, _ = O.kitti_eval_sample(fullframe_frame(kind))
+    with torch.no_grad():
+        preds = O.cmfsm_forward(left.unsqueeze(0), right.unsqueeze(0), cmfsm_sd)
+    for i, (p, w32, t64) in enumerate(zip(preds, want, w64)):
+        g = p[..., ::4, ::4].numpy()
+        assert g.shape == w32.shape
+        assert np.abs(g - w32).max() <= 2e-3 and np.abs(g - w32).mean() <= 1e-4          # same arithmetic up to thread order
+        assert np.abs(g - t64).max() <= 2e-3

@@ -34,17 +34,42 @@ __device__ __forceinline__ void gn_affine(float mean, float rstd, float gamma, f
     sh = __builtin_fmaf(-mean, a, beta);
 }
 
-// Statistics are accumulated as sums of d = x - K and d^2 around a PIVOT K = the span's first element, and the variance is
+// Statistics are accumulated as sums of d = x - K and d^2 around a PIVOT K (gn_pivot below), and the variance is
 // E[d^2] - E[d]^2: the textbook E[x^2] - E[x]^2 cancels catastrophically when |mean| >> std -- the SPP branches normalise
 // maps of 2..6 pixels per group whose values differ in the third digit, and round 2's kernels lost three digits of the
 // normalised value there (measured: 1.2e-3 relative against 1.9e-5 for torch's Welford form, which put the whole
 // encoder's low-resolution feature 12x further from the fp64 truth than the reference's fp32).
+// Round 4: a pivot taken from ONE element makes the accuracy of a whole group hang on that element -- an outlier
+// there (|K - mean| >> std: an activation spike in the corner, a border pixel) brings the cancellation back for every
+// element of the group.  The pivot is now a TRIMMED mean of 16 elements spread evenly over the span (mid-points of its
+// sixteenths; smallest and largest sample dropped), or the plain mean of a span shorter than 16: a single outlier among the
+// samples is discarded outright, and a typical span gives |K - mean| ~ std / 4.  Every workgroup of a span and the
+// finishing stage evaluate the same expression in the same order, so they agree bit for bit.
+__device__ __forceinline__ float gn_pivot(const float* __restrict__ p, long long n) {
+    float s = 0.f;
+    if (n < 16) {
+        for (long long i = 0; i < n; ++i) s += p[i];
+        return s / (float)n;
+    }
+    const long long st = n / 16;
+    float lo = p[st >> 1], hi = lo;
+    s = lo;
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+        const float v = p[(long long)j * st + (st >> 1)];
+        s += v;
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    return (s - lo - hi) * (1.0f / 14.0f);
+}
+
 // stage 1: partial (sum d, sum d^2) of chunk `blockIdx.x` of span `blockIdx.y` (= b*32+g); span = n contiguous floats
 __global__ __launch_bounds__(THREADS) void gn_stats_partial(const float* __restrict__ x, float* __restrict__ part,
                                                             long long n, int nchunks) {
     __shared__ float sm[2 * THREADS / 64];
     const float* p = x + (size_t)blockIdx.y * n;
-    const float K = p[0];
+    const float K = gn_pivot(p, n);
     const long long beg = (long long)blockIdx.x * CHUNK;
     const long long end = beg + CHUNK < n ? beg + CHUNK : n;
     float s = 0.f, q = 0.f;
@@ -73,7 +98,7 @@ __global__ void gn_stats_final(const float* __restrict__ x, const float* __restr
     double s = 0.0, q = 0.0;
     for (int c = 0; c < nchunks; ++c) { s += part[((size_t)i * nchunks + c) * 2]; q += part[((size_t)i * nchunks + c) * 2 + 1]; }
     const double dm = s / (double)n;                    // mean of x - K
-    const double mean = (double)x[(size_t)i * n] + dm;
+    const double mean = (double)gn_pivot(x + (size_t)i * n, n) + dm;
     double var = q / (double)n - dm * dm;
     if (var < 0.0) var = 0.0;
     mean_rstd[2 * i] = (float)mean;
@@ -449,8 +474,8 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         const int c = g * cpg + cig;
         const size_t base = ((size_t)b * C + c) * S;
         const auto xr = slice_rsrc(x + base + (size_t)v0 * 4, v1 - v0);
-        // pivot of the span (see gn_stats_partial): its first element, the same for every member of the cluster
-        const float K = x[((size_t)b * C + (size_t)g * cpg) * S];
+        // pivot of the span (see gn_pivot): the same for every member of the cluster
+        const float K = gn_pivot(x + ((size_t)b * C + (size_t)g * cpg) * S, (long long)cpg * S);
         const unsigned nslice = (unsigned)(v1 - v0), vidx = (unsigned)(wave * MAXV4 * 64 + lane);
         float4 v[MAXV4];
         float s = 0.f, q = 0.f;

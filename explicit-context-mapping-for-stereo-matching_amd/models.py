@@ -30,6 +30,21 @@ NUM_GROUPS = 32  # cmfsm.py:31-33
 # set `models.EXPLICIT_COST_VOLUME = True`.
 import os as _os
 EXPLICIT_COST_VOLUME = _os.environ.get("ECM_EXPLICIT_COST_VOLUME", "0") == "1"
+# Nothing in this package falls back to a vendor library silently: a layer outside the native kernels raises unless
+# ECM_ALLOW_FALLBACK=1, and every time a slower-than-designed path IS taken (that opt-in, or a dilated stage whose map is
+# not divisible by its dilation and therefore runs on the direct dilated kernels instead of phase planes) an entry lands
+# here and a warning is issued once per cause.
+ALLOW_FALLBACK = _os.environ.get("ECM_ALLOW_FALLBACK", "0") == "1"
+SLOW_PATH_EVENTS = []
+_WARNED = set()
+
+
+def _note_slow_path(kind, detail):
+    SLOW_PATH_EVENTS.append((kind,) + tuple(detail))
+    if kind not in _WARNED:
+        _WARNED.add(kind)
+        import warnings
+        warnings.warn(f"ecm: {kind} {detail}: running on the slower native path (recorded in models.SLOW_PATH_EVENTS)")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -54,8 +69,8 @@ class HipGroupNorm(nn.GroupNorm):
     def forward(self, x):
         return ops.group_norm_act(x, self.weight, self.bias, None, False)
 
-    def fused(self, x, skip=None, relu=False):
-        return ops.group_norm_act(x, self.weight, self.bias, skip, relu)
+    def fused(self, x, skip=None, relu=False, head=0):
+        return ops.group_norm_act(x, self.weight, self.bias, skip, relu, head)
 
 
 class HipReLU(nn.ReLU):
@@ -66,7 +81,8 @@ class EncConv2d(nn.Conv2d):
     """nn.Conv2d of the encoder (same parameters, hence the reference's state_dict keys).  Every layer shape of the
     registered architectures -- 3x3 with stride 1|2 and dilation 1|2|4, the 3-channel stem, the 64/128/320/384-channel
     stages, the 1x1 projections -- runs on the MFMA implicit-GEMM family (ops.conv2d: forward, data and weight gradient);
-    a configuration outside it (none in the registered models) would fall to PyTorch-ROCm."""
+    a configuration outside it (none in the registered models) RAISES: the vendor-library path (nn.Conv2d's own forward on
+    MIOpen) exists only behind ECM_ALLOW_FALLBACK=1, so a slow path can never be taken unseen."""
 
     def _native(self):
         kh, kw = self.kernel_size
@@ -81,6 +97,12 @@ class EncConv2d(nn.Conv2d):
             return ops.conv2d_planes(x, self.weight, fork)
         if self._native():     # raises on CPU tensors, like every op
             return ops.conv2d(x, self.weight, self.stride[0], self.dilation[0], fork=fork)
+        if not ALLOW_FALLBACK:
+            raise RuntimeError(
+                f"EncConv2d({self.in_channels}->{self.out_channels}, k={self.kernel_size}, s={self.stride}, d={self.dilation}, "
+                f"groups={self.groups}, bias={self.bias is not None}) is outside the native 2-D family (ops.conv2d_supported); "
+                "set ECM_ALLOW_FALLBACK=1 to run it on PyTorch-ROCm's own convolution instead")
+        SLOW_PATH_EVENTS.append(("miopen_conv2d", self.in_channels, self.out_channels, self.kernel_size))
         y = super().forward(x)
         return (y, x) if fork else y
 
@@ -289,6 +311,11 @@ class feature_extraction(nn.Module):
         ok = (ops.WINOGRAD and d > 1 and x.shape[-2] % d == 0 and x.shape[-1] % d == 0 and x.shape[-1] // d >= 2
               and all(m.kernel_size == (3, 3) and m.stride == (1, 1) and m.dilation == (d, d) and m.padding == (d, d) for m in convs))
         if not ok:
+            if d > 1 and ops.WINOGRAD:
+                # still this library's kernels (the direct dilated 3x3 family), but not the designed fast path: made visible.
+                # Only a map whose height / width is not a multiple of the dilation gets here (e.g. the /16 nets' dilation-4
+                # stage on a 384x1248 KITTI frame: 24 x 78); no registered architecture does at the SceneFlow size.
+                _note_slow_path("dilated_stage_unphased", (d, tuple(x.shape)))
             return layer(x)
         return ops.phase_merge(layer(ops.phase_split(x, d)), d)
 
@@ -297,9 +324,15 @@ class feature_extraction(nn.Module):
         gradient is then folded into the map's gradient in place (ops.fork_head) instead of through a zero-padded copy."""
         output_all = _seq_fused(self.firstconv, x)
         output_head = None
-        if head is not None:
-            output_all, output_head = ops.fork_head(output_all, head)
-        output_rt = self.layer1(_seq_fused(self.secondconv, output_all))
+        if head is not None and isinstance(self.secondconv[0], HipGroupNorm):
+            # the map's whole-batch consumer is secondconv's GroupNorm + ReLU: that node hands the head slice out and folds
+            # its gradient into its own data gradient (ops.GroupNormAct `head`)
+            y, output_head = self.secondconv[0].fused(output_all, None, True, head=head)
+            output_rt = self.layer1(_seq_fused(self.secondconv, y, start=2))
+        else:
+            if head is not None:
+                output_all, output_head = ops.fork_head(output_all, head)
+            output_rt = self.layer1(_seq_fused(self.secondconv, output_all))
         output_raw = self.layer2(output_rt)
         if self._raw_is_layer3:                       # cmfsm_sub_16.py:205-207
             output_raw = self._run_layer(self.layer3, output_raw)

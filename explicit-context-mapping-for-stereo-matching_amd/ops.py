@@ -444,8 +444,10 @@ def _wino_pack_both(w, kd):
 
 def _wino_pack_fwd(ctx, x, w, kd):
     """Forward layout of w; in a pass that will need the data gradient, also the backward layout (stored on ctx)."""
+    # (grad mode is always OFF inside autograd.Function.forward, so it cannot be the test; needs_input_grad is all-False under
+    # no_grad / in eval and True for exactly the layers whose backward will run the data-gradient kernel)
     ctx.packed_b = None
-    if torch.is_grad_enabled() and x.requires_grad and not _FROZEN_DEPTH and not torch.cuda.is_current_stream_capturing():
+    if ctx.needs_input_grad[0] and not _FROZEN_DEPTH and not torch.cuda.is_current_stream_capturing():
         pf, ctx.packed_b = _wino_pack_both(w, kd)
         return pf
     return _wino_pack(w, kd, False)
@@ -520,8 +522,11 @@ class ForkHead(torch.autograd.Function):
     """x -> (alias of x, x[:n]): one consumer of the whole batch and one of its first n samples (the encoder's full-resolution
     map: the next encoder layer takes both images, the ECM weights only the left ones, cmfsm.py:657-664).  Autograd's own
     route for that is a zero-filled full-size tensor, a copy of the slice gradient into it and a full-size add (2.8 GB of
-    traffic at batch 4); here the slice gradient is added INTO the first n samples of the full gradient, which this node
-    owns (it is the fresh output of the consuming layer's data-gradient kernel)."""
+    traffic at batch 4); here the full gradient is copied once and the slice gradient added into the copy's first n samples.
+    The incoming gradient itself is never written: autograd does not promise that a node owns it (a tensor hook,
+    `retain_grad`, a producer that returns one tensor for two inputs, or a `retain_graph` replay may hold the same object).
+    Where the consumer of the whole batch is a GroupNorm (cmfsm's encoder) the fork lives inside that node instead
+    (GroupNormAct `head`), which adds into its own fresh output with no copy at all."""
 
     @staticmethod
     def forward(ctx, x, n):
@@ -535,11 +540,9 @@ class ForkHead(torch.autograd.Function):
             return g_full, None
         if g_full is None:
             raise RuntimeError("ForkHead: the full-batch consumer produced no gradient")   # not a configuration of this model
-        g_full = _c(g_full)
-        if g_full._is_view():                                # someone else's memory shows through it: do not write into that
-            g_full = g_full.clone()
-        g_full[:ctx.n].add_(g_head)
-        return g_full, None
+        out = g_full.clone(memory_format=torch.contiguous_format)
+        out[:ctx.n].add_(g_head)
+        return out, None
 
 
 def fork_head(x, n):
@@ -611,7 +614,9 @@ def join_side_streams():
 
 def _on_side(fn, w, *operands):
     dev = operands[0].device
-    if (not WGRAD_OVERLAP or w is None or not w.is_leaf or w._backward_hooks or torch.cuda.is_current_stream_capturing()):
+    if (not WGRAD_OVERLAP or w is None or not w.is_leaf or w._backward_hooks or torch.cuda.is_current_stream_capturing()
+            or torch.is_grad_enabled()          # backward(create_graph=True): AccumulateGrad CLONES the gradient on the main stream
+            or not w.is_contiguous()):          # layout outside AccumulateGrad's stealing contract: it clones there too
         return fn()
     st = _SIDE.get(dev.index)
     if st is None:
@@ -1046,11 +1051,24 @@ def _gn_call(name, *args):
         raise
 
 
+def _gn_capturing():
+    """During HIP-graph capture the kept exchange buffer must not be used: `torch.cuda.graph` captures on ONE
+    stream for every graph, so the (device, stream) cache would hand a buffer that was allocated in -- and preset by -- the
+    FIRST graph to every later capture, whose kernels would then depend on another graph's replay having run (and two graphs
+    replayed concurrently would share the buffer).  A captured GroupNorm therefore takes the stateless entry points
+    (ecm_gn3d_fwd / _bwd: exchange memory inside the call's own scratch, one memset node per launch in the graph)."""
+    return torch.cuda.is_current_stream_capturing()
+
+
 class GroupNormAct(torch.autograd.Function):
     """y = relu?( GroupNorm32(x)*gamma+beta (+ skip) )  (cmfsm.py:58 + ReLU/residual at 287-299, 606-613, 685-693)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, skip, relu):
+    def forward(ctx, x, gamma, beta, skip, relu, head=0):
+        """head > 0 (a fork, cf. _fork_out): also returns x[:head] for a second consumer of the first `head` samples of the
+        INPUT (the encoder's full-resolution map: the ECM weights read the left images' half, cmfsm.py:657-664); backward adds
+        that consumer's gradient into the first `head` samples of gx -- a tensor this node has just produced and nobody else
+        has seen, so the in-place add cannot touch memory another holder relies on."""
         _chk(x, gamma, beta, skip)
         x, gamma, beta = _c(x), _c(gamma), _c(beta)
         skip = _c(skip) if skip is not None else None
@@ -1060,17 +1078,26 @@ class GroupNormAct(torch.autograd.Function):
         nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
         scratch = _scratch(nb, x.device)
         y = _empty_like(x)
-        cl = _gn_cluster(B, x.device)
-        _gn_call("ecm_gn3d_fwd_p", _p(x), _p(gamma), _p(beta), _p(skip), _p(y), _p(stats), _p(scratch), C.c_longlong(nb),
-                 _p(cl), C.c_longlong(cl.numel()), B, Cc, C.c_longlong(S), int(relu), C.c_float(GN_EPS), _stream())
+        if _gn_capturing():
+            _gn_call("ecm_gn3d_fwd", _p(x), _p(gamma), _p(beta), _p(skip), _p(y), _p(stats), _p(scratch), C.c_longlong(nb),
+                     B, Cc, C.c_longlong(S), int(relu), C.c_float(GN_EPS), _stream())
+        else:
+            cl = _gn_cluster(B, x.device)
+            _gn_call("ecm_gn3d_fwd_p", _p(x), _p(gamma), _p(beta), _p(skip), _p(y), _p(stats), _p(scratch), C.c_longlong(nb),
+                     _p(cl), C.c_longlong(cl.numel()), B, Cc, C.c_longlong(S), int(relu), C.c_float(GN_EPS), _stream())
         # ReLU mask in backward: recomputed from x unless a skip was added (then the output y is needed)
         ctx.save_for_backward(x, stats, gamma, beta, y if (relu and skip is not None) else None)
-        ctx.relu, ctx.has_skip = relu, skip is not None
+        ctx.relu, ctx.has_skip, ctx.head = relu, skip is not None, int(head)
+        if head:
+            ctx.set_materialize_grads(False)
+            return y, x[:head]
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_head=None):
         x, stats, gamma, beta, y = ctx.saved_tensors
+        if gy is None:
+            raise RuntimeError("GroupNormAct: the normalised output produced no gradient")     # not a configuration of these models
         gy = _c(gy)
         B, Cc = x.shape[:2]
         S = x.numel() // (B * Cc)
@@ -1081,11 +1108,18 @@ class GroupNormAct(torch.autograd.Function):
         ggamma, gbeta = _empty_like(gamma), _empty_like(gamma)
         nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
         scratch = _scratch(nb, x.device)
-        cl = _gn_cluster(B, x.device)
-        _gn_call("ecm_gn3d_bwd_p", _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(gy), _p(gx),
-                 _p(gskip if (ctx.has_skip and ctx.relu) else None), _p(ggamma), _p(gbeta), _p(scratch),
-                 C.c_longlong(nb), _p(cl), C.c_longlong(cl.numel()), B, Cc, C.c_longlong(S), int(ctx.relu), _stream())
-        return gx, ggamma, gbeta, gskip, None
+        if _gn_capturing():
+            _gn_call("ecm_gn3d_bwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(gy), _p(gx),
+                     _p(gskip if (ctx.has_skip and ctx.relu) else None), _p(ggamma), _p(gbeta), _p(scratch),
+                     C.c_longlong(nb), B, Cc, C.c_longlong(S), int(ctx.relu), _stream())
+        else:
+            cl = _gn_cluster(B, x.device)
+            _gn_call("ecm_gn3d_bwd_p", _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(gy), _p(gx),
+                     _p(gskip if (ctx.has_skip and ctx.relu) else None), _p(ggamma), _p(gbeta), _p(scratch),
+                     C.c_longlong(nb), _p(cl), C.c_longlong(cl.numel()), B, Cc, C.c_longlong(S), int(ctx.relu), _stream())
+        if g_head is not None:
+            gx[:ctx.head].add_(g_head)          # gx is this node's own fresh output (see forward)
+        return gx, ggamma, gbeta, gskip, None, None
 
 
 FLYING3D_MEAN, FLYING3D_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # cmf/loader/Flying3d.py:26-27
@@ -1224,8 +1258,11 @@ def stereo_loss3(preds, gt, maxdisp=192, weights=(0.5, 0.7, 1.0)):
     return StereoLoss3.apply(p1, p2, p3, gt, float(maxdisp), *map(float, weights))
 
 
-def group_norm_act(x, gamma, beta, skip=None, relu=False):
-    return GroupNormAct.apply(x, gamma, beta, skip, bool(relu))
+def group_norm_act(x, gamma, beta, skip=None, relu=False, head=0):
+    """head > 0: returns (y, x[:head]) -- see GroupNormAct.forward."""
+    if head and not (torch.is_grad_enabled() and x.requires_grad):
+        return GroupNormAct.apply(x, gamma, beta, skip, bool(relu), 0), x[:head]
+    return GroupNormAct.apply(x, gamma, beta, skip, bool(relu), int(head))
 
 
 def gn_cluster_mode(mode=-1):

@@ -96,3 +96,70 @@ def test_winograd_range_check_at_the_descriptor_bound(ecm):
                  D, H, W, 3, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert not ecm.ops._wino_ok(torch.empty(0, 32, D, H, W, device="meta"))
     assert ecm.ops._wino_ok(torch.empty(0, 32, 64, 512, 512, device="meta"))
+
+
+@pytest.mark.parametrize("kd,Co,Ci", [(3, 32, 32), (3, 32, 64), (3, 24, 40), (1, 32, 32), (1, 128, 320), (1, 480, 32), (1, 20, 36)])
+def test_wino_pack_weight2_equals_the_two_single_packs(ecm, kd, Co, Ci):
+    """ecm_conv_wino_pack_weight2 (forward + data-gradient layout from one launch) against two ecm_conv_wino_pack_weight
+    launches, bit for bit, ragged channel counts included."""
+    import ctypes as C
+    lib = ecm._lib
+    g = torch.Generator(device="cuda").manual_seed(kd * 1000 + Co + Ci)
+    w = torch.randn((Co, Ci) + ((3, 3, 3) if kd == 3 else (3, 3)), device="cuda", generator=g)
+    nf, nb = lib.query("ecm_conv_wino_packed_floats", Ci, Co, kd), lib.query("ecm_conv_wino_packed_floats", Co, Ci, kd)
+    both = torch.full((nf + nb,), float("nan"), device="cuda")
+    pf, pb = torch.full((nf,), float("nan"), device="cuda"), torch.full((nb,), float("nan"), device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    lib.call("ecm_conv_wino_pack_weight2", p(w), p(both), Co, Ci, kd, st)
+    lib.call("ecm_conv_wino_pack_weight", p(w), p(pf), Co, Ci, kd, 0, st)
+    lib.call("ecm_conv_wino_pack_weight", p(w), p(pb), Co, Ci, kd, 1, st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(both).all()
+    assert torch.equal(both[:nf], pf) and torch.equal(both[nf:], pb)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_training_backward_uses_the_layout_packed_in_forward(ecm, dim):
+    """A layer's training step packs its weight ONCE (forward + data-gradient layout together); the backward must find the
+    second layout on the autograd context instead of launching another pack in front of its data-gradient kernel -- counted
+    on the C-ABI launches themselves.  Under no_grad only the forward layout is packed."""
+    ops, lib = ecm.ops, ecm._lib
+    g = torch.Generator(device="cuda").manual_seed(3)
+    if dim == 3:
+        w = torch.randn(32, 32, 3, 3, 3, device="cuda", generator=g).requires_grad_()
+        x = torch.randn(1, 32, 6, 10, 12, device="cuda", generator=g).requires_grad_()
+        f = lambda: ops.conv3d_k3(x, w, 1)
+    else:
+        w = torch.randn(32, 32, 3, 3, device="cuda", generator=g).requires_grad_()
+        x = torch.randn(1, 32, 20, 24, device="cuda", generator=g).requires_grad_()
+        f = lambda: ops.conv2d(x, w, 1, 1)
+    for name in ("ecm_conv_wino_pack_weight", "ecm_conv_wino_pack_weight2", "ecm_conv_wino_fwd"):
+        lib.enable_timer(name)
+    y = f()
+    y.sum().backward()
+    torch.cuda.synchronize()
+    t = lib.disable_timers()
+    assert len(t["ecm_conv_wino_pack_weight2"]) == 1 and len(t["ecm_conv_wino_pack_weight"]) == 0, {k: len(v) for k, v in t.items()}
+    assert len(t["ecm_conv_wino_fwd"]) == 2                                   # forward + data gradient
+    gx = x.grad.clone()
+    # same gradients as with the layouts packed separately (an in-place weight write between forward and backward
+    # invalidates the stored layout: the backward then packs afresh)
+    x.grad = None
+    for name in ("ecm_conv_wino_pack_weight", "ecm_conv_wino_pack_weight2"):
+        lib.enable_timer(name)
+    y = f()
+    with torch.no_grad():
+        w.add_(0.0)                                                            # bumps the version counter
+    y.sum().backward()
+    torch.cuda.synchronize()
+    t = lib.disable_timers()
+    assert len(t["ecm_conv_wino_pack_weight2"]) == 1 and len(t["ecm_conv_wino_pack_weight"]) == 1
+    assert torch.equal(x.grad, gx)
+    lib.enable_timer("ecm_conv_wino_pack_weight")
+    lib.enable_timer("ecm_conv_wino_pack_weight2")
+    with torch.no_grad():
+        f()
+    torch.cuda.synchronize()
+    t = lib.disable_timers()
+    assert len(t["ecm_conv_wino_pack_weight2"]) == 0 and len(t["ecm_conv_wino_pack_weight"]) == 1

@@ -103,3 +103,74 @@ def test_layer_used_twice_accumulates_correctly(ecm):
             assert torch.equal(run(), ref)
     finally:
         ops.enable_wgrad_overlap(prev)
+
+
+def test_gradients_are_complete_on_the_current_stream_right_after_backward(ecm):
+    """The join itself: the autograd-engine callback queued by ops._on_side must make the CURRENT stream wait for
+    the side stream at the end of backward.  Here nothing synchronises the device between backward() and the readers: the
+    gradients are cloned / consumed by an optimizer step on the current stream straight away, with a long queue on the side
+    stream (several big weight-gradient kernels behind each other), and must equal the no-overlap run bit for bit."""
+    ops = ecm.ops
+    torch.manual_seed(9)
+    ws = [(torch.randn(32, 32, 3, 3, 3, device="cuda") * 0.05).requires_grad_() for _ in range(6)]
+    x0 = torch.randn(2, 32, 24, 72, 120, device="cuda")
+
+    def run(read):
+        for w in ws:
+            w.grad = None
+        x = x0
+        for w in ws:                                           # a chain: backward launches six weight gradients back to back
+            x = ops.conv3d_k3(x, w, 1)
+        x.square().mean().backward()
+        return read()                                          # NO torch.cuda.synchronize() before the read
+
+    clone = lambda: [w.grad.clone() for w in ws]
+    prev = ops.enable_wgrad_overlap(False)
+    try:
+        ref = run(clone)
+        torch.cuda.synchronize()
+        ops.enable_wgrad_overlap(True)
+        if not ops.WGRAD_OVERLAP:
+            pytest.skip("ECM_WGRAD_OVERLAP=0 in the environment")
+        ops._SIDE.clear()
+        for _ in range(3):
+            got = run(clone)
+            assert ops._SIDE, "no weight gradient went to the side stream"
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b)
+        # an optimizer step right behind backward (the plain-optimizer path under ECM_WGRAD_OVERLAP=1)
+        start = [w.detach().clone() for w in ws]
+
+        def sgd():
+            with torch.no_grad():
+                out = [w - 0.1 * w.grad for w in ws]
+            return out
+        after = run(sgd)
+        for a, s0, g in zip(after, start, ref):
+            assert torch.equal(a, s0 - 0.1 * g)
+    finally:
+        ops.enable_wgrad_overlap(prev)
+
+
+def test_create_graph_and_odd_layouts_stay_on_the_main_stream(ecm):
+    """backward(create_graph=True) makes AccumulateGrad CLONE the gradient on the main stream (no join against a side-stream
+    writer), and so does a weight whose layout is outside its stealing contract: both must compute on the main stream."""
+    ops = ecm.ops
+    prev = ops.enable_wgrad_overlap(True)
+    try:
+        if not ops.WGRAD_OVERLAP:
+            pytest.skip("ECM_WGRAD_OVERLAP=0 in the environment")
+        x = torch.randn(1, 32, 8, 16, 32, device="cuda", requires_grad=True)
+        w = (torch.randn(32, 32, 3, 3, 3, device="cuda") * 0.05).requires_grad_()
+        ops._SIDE.clear()
+        ops.conv3d_k3(x, w, 1).sum().backward(create_graph=True)
+        assert not ops._SIDE
+        wt = (torch.randn(32, 32, 3, 3, 3, device="cuda") * 0.05).permute(1, 0, 2, 3, 4).requires_grad_()     # non-contiguous leaf
+        assert wt.is_leaf and not wt.is_contiguous()
+        ops.conv3d_k3(x, wt, 1).sum().backward()
+        assert not ops._SIDE
+        torch.cuda.synchronize()
+        ref = torch.autograd.grad(torch.nn.functional.conv3d(x, wt.detach(), padding=1).sum(), x)[0]
+        assert ref.shape == x.shape
+    finally:
+        ops.enable_wgrad_overlap(prev)

@@ -715,6 +715,22 @@ struct GnControl {
     unsigned* status_host = nullptr;                    // pinned, mapped: the kernels OR a bit in on a timeout
     unsigned* status_dev = nullptr;
     bool env_read = false;
+    // Two cluster launches that run CONCURRENTLY (two streams of one process) can starve each other: each keeps workgroups
+    // resident that wait for cluster members the other launch's waiting workgroups leave no room for -- both then sit in
+    // their bounded waits (found in round 4 by replaying two captured graphs on two streams: ~85 launches x 2 s).  Cluster
+    // launches of one process are therefore ORDERED across streams on the host.  As long as every cluster launch of a device
+    // comes from one stream nothing is done.  The first launch from another stream waits for the device to drain once (the
+    // earlier stream may no longer exist -- HIP aborts on a stale handle, so it is never touched again) and switches the
+    // device to multi-stream mode: from then on an event is recorded behind every cluster launch and a launch on a stream
+    // other than the previous one's waits for it.  `launch_mu` keeps [wait, launch, record] atomic between threads.  A
+    // stream that is being captured into a graph never takes the cluster kernels at all (no such ordering can be recorded
+    // against streams outside the capture): it gets the two-stage ones.
+    std::mutex launch_mu;
+    static constexpr int MAX_DEV = 32;
+    hipStream_t last_stream[MAX_DEV] = {};
+    bool have_last[MAX_DEV] = {};
+    bool multi[MAX_DEV] = {};
+    hipEvent_t order_ev[MAX_DEV] = {};
 };
 GnControl& gn_ctl() { static GnControl c; return c; }
 
@@ -760,6 +776,28 @@ inline FusedLaunch fused_prepare(float* scratch, bool preset, int B, int C, long
     if (mode == 2) L.g.grid -= L.g.grid % L.g.cl;                    // static ids: whole clusters only
     if (mode == 3) L.g.grid = L.g.cl > 1 ? L.g.cl - 1 : 1;           // fault injection: a cluster can never be complete
     if (mode == 3 && L.g.cl == 1) return L;
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+        else if (cs != hipStreamCaptureStatusNone) return L;        // captured: two-stage kernels (see GnControl)
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < GnControl::MAX_DEV) {      // (launch_mu is held by the caller)
+            if (c.have_last[dev] && c.last_stream[dev] != st) {
+                if (!c.multi[dev]) {
+                    c.multi[dev] = true;
+                    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+                    if (hipEventCreateWithFlags(&c.order_ev[dev], hipEventDisableTiming) != hipSuccess) {
+                        c.order_ev[dev] = nullptr;
+                        (void)hipGetLastError();
+                    }
+                } else if (c.order_ev[dev]) {
+                    if (hipStreamWaitEvent(st, c.order_ev[dev], 0) != hipSuccess) (void)hipGetLastError();
+                }
+            }
+            c.last_stream[dev] = st;
+            c.have_last[dev] = true;
+        }
+    }
     L.ctl.dynamic = mode == 2 ? 0 : 1;
     L.ctl.slots = reinterpret_cast<unsigned long long*>(scratch);
     const size_t nslots = (size_t)L.g.nspans * L.g.cl;
@@ -775,17 +813,32 @@ inline FusedLaunch fused_prepare(float* scratch, bool preset, int B, int C, long
     return L;
 }
 
+// behind a cluster launch (launch_mu held): in multi-stream mode, the event the next launch on another stream waits for
+inline void fused_launched(hipStream_t st) {
+    GnControl& c = gn_ctl();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GnControl::MAX_DEV || !c.multi[dev]) return;
+    if (!c.order_ev[dev]) {                                 // creation failed earlier: fall back to draining the device
+        (void)hipDeviceSynchronize();
+        return;
+    }
+    if (hipEventRecord(c.order_ev[dev], st) != hipSuccess) (void)hipGetLastError();
+}
+
 template <bool RELU, bool SKIP>
 int launch_fused_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, float* mean_rstd,
                      float* scratch, bool preset, int B, int C, long long S, float eps, hipStream_t st) {
     auto kern = gn_fused_fwd<RELU, SKIP>;
     static int resident = -1;
+    std::lock_guard<std::mutex> order(gn_ctl().launch_mu);
     if (resident < 0) resident = resident_workgroups(kern);
     const FusedLaunch L = fused_prepare(scratch, preset, B, C, S, FWD_MAXV4, resident, st);
     if (L.rc) return L.rc;
     hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), 0, st, x, gamma, beta, skip, y, mean_rstd, L.ctl, C,
                        S, L.g.cpg, L.g.wpc, L.g.nspans, L.g.v4_per_wg, eps);
-    return ECM_LAUNCH_RESULT();
+    const int rc = ECM_LAUNCH_RESULT();
+    fused_launched(st);
+    return rc;
 }
 
 template <int MASK, int GSKIP>
@@ -794,12 +847,15 @@ int launch_fused_bwd(const float* x, const float* mean_rstd, const float* gamma,
                      hipStream_t st) {
     auto kern = gn_fused_bwd<MASK, GSKIP>;
     static int resident = -1;
+    std::lock_guard<std::mutex> order(gn_ctl().launch_mu);
     if (resident < 0) resident = resident_workgroups(kern);
     const FusedLaunch L = fused_prepare(scratch, preset, B, C, S, BWD_MAXV4, resident, st);
     if (L.rc) return L.rc;
     hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), 0, st, x, mean_rstd, gamma, beta, y, gy, gx, gskip,
                        chan, L.ctl, C, S, L.g.cpg, L.g.wpc, L.g.nspans, L.g.v4_per_wg);
-    return ECM_LAUNCH_RESULT();
+    const int rc = ECM_LAUNCH_RESULT();
+    fused_launched(st);
+    return rc;
 }
 
 // A cluster launch that timed out earlier leaves the sticky word set: every later GroupNorm call fails until cleared.

@@ -1056,7 +1056,9 @@ def _gn_capturing():
     stream for every graph, so the (device, stream) cache would hand a buffer that was allocated in -- and preset by -- the
     FIRST graph to every later capture, whose kernels would then depend on another graph's replay having run (and two graphs
     replayed concurrently would share the buffer).  A captured GroupNorm therefore takes the stateless entry points
-    (ecm_gn3d_fwd / _bwd: exchange memory inside the call's own scratch, one memset node per launch in the graph)."""
+    (ecm_gn3d_fwd / _bwd), and the library itself gives a capturing stream the two-stage kernels -- no inter-workgroup
+    waits, no exchange memory -- because two graphs replayed concurrently could otherwise starve each other's clusters
+    (csrc/gn3d.hip: GnControl)."""
     return torch.cuda.is_current_stream_capturing()
 
 

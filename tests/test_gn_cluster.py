@@ -117,7 +117,8 @@ def test_two_captured_graphs_replayed_in_any_order(ecm):
     """the GroupNorm exchange buffer used to be cached per (device, stream) during capture too -- every
     torch.cuda.graph capture runs on the same stream, so a second graph found the first graph's buffer and captured no
     preset: replaying it FIRST ran the cluster kernels on uninitialised memory (2 s time-outs, NaN, sticky ECM_EASYNC).
-    Captured GroupNorms now carry their own exchange memory (stateless entry points)."""
+    Captured GroupNorms no longer touch the kept buffer (stateless entry points), and a capturing stream gets the two-stage
+    kernels, so that two graphs replayed CONCURRENTLY cannot starve each other's clusters either."""
     from importlib import import_module
     D = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
     torch.manual_seed(4)
@@ -125,12 +126,18 @@ def test_two_captured_graphs_replayed_in_any_order(ecm):
     g = torch.Generator(device="cuda").manual_seed(1)
     l1, r1 = (torch.randn(1, 3, 256, 512, device="cuda", generator=g) for _ in range(2))
     l2, r2 = (torch.randn(1, 3, 256, 256, device="cuda", generator=g) for _ in range(2))
-    with torch.no_grad():
-        want1 = [o.clone() for o in model(l1, r1)]
-        want2 = [o.clone() for o in model(l2, r2)]
+    old = ecm.ops.gn_cluster_mode(0)                      # a captured GroupNorm runs the two-stage kernels: like against like
+    try:
+        with torch.no_grad():
+            want1 = [o.clone() for o in model(l1, r1)]
+            want2 = [o.clone() for o in model(l2, r2)]
+    finally:
+        ecm.ops.gn_cluster_mode(old)
     ecm.ops._GN_CLUSTER.clear()                           # as in a fresh process: nothing preset before the captures
     g1 = D.GraphedForward(model, l1, r1, warmup=1)
+    print("graph 1 captured", flush=True)
     g2 = D.GraphedForward(model, l2, r2, warmup=1)
+    print("graph 2 captured", flush=True)
     out2 = [o.clone() for o in g2(l2, r2)]                # the SECOND graph first
     out1 = [o.clone() for o in g1(l1, r1)]
     torch.cuda.synchronize()
@@ -138,6 +145,7 @@ def test_two_captured_graphs_replayed_in_any_order(ecm):
     for a, b in zip(out1 + out2, want1 + want2):
         assert torch.isfinite(a).all()
         torch.testing.assert_close(a, b, rtol=0, atol=1e-4)
+    print("ordered replays ok", flush=True)
     # two graphs replayed concurrently on different streams share nothing
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     for s in (s1, s2):
@@ -150,3 +158,35 @@ def test_two_captured_graphs_replayed_in_any_order(ecm):
     ecm.ops.check_async_errors()
     for a, b in zip(list(g1.out) + list(g2.out), want1 + want2):
         torch.testing.assert_close(a, b, rtol=0, atol=1e-4)
+
+
+def test_two_eager_forwards_of_different_shapes_on_two_streams(ecm):
+    """Two model forwards of DIFFERENT sizes issued on two streams of one process (cluster launches of different geometry in
+    flight together): this is what starved the clusters in round 4 before cluster launches were ordered across streams on
+    the host.  Must finish far inside the bounded waits, equal the one-stream results, and leave no asynchronous error."""
+    import time
+    torch.manual_seed(4)
+    model = ecm.get_model("cmfsm").cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    a = [torch.randn(1, 3, 256, 512, device="cuda", generator=g) for _ in range(2)]
+    b = [torch.randn(1, 3, 256, 256, device="cuda", generator=g) for _ in range(2)]
+    with torch.no_grad():
+        want_a, want_b = model(*a)[2].clone(), model(*b)[2].clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = []
+    with torch.no_grad():
+        for _ in range(3):
+            with torch.cuda.stream(s1):
+                oa = model(*a)[2]
+            with torch.cuda.stream(s2):
+                ob = model(*b)[2]
+            outs.append((oa, ob))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ecm.ops.check_async_errors()
+    assert dt < 20.0, f"{dt:.1f} s for six small forwards: cluster launches ran into their bounded waits"
+    for oa, ob in outs:
+        torch.testing.assert_close(oa, want_a, rtol=0, atol=1e-4)
+        torch.testing.assert_close(ob, want_b, rtol=0, atol=1e-4)

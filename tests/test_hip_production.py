@@ -280,9 +280,13 @@ def test_train_step_b4_collapsed_vs_explicit(ecm, B, H, W):
     (la, ga), (lb, gb) = res["collapsed"], res["explicit"]
     assert la == la and abs(la - lb) <= 1e-4 * abs(lb), (la, lb)
     worst = max(((float((ga[k] - gb[k]).abs().max()) / (float(gb[k].abs().max()) + 1e-30)), k) for k in ga)
+    worst_l2 = max(((float((ga[k] - gb[k]).norm()) / (float(gb[k].norm()) + 1e-30)), k) for k in ga)
     # everything after dres0.0 is the same kernels on inputs that differ by fp32 rounding of the first conv (~1e-6
     # relative), which kink flips of ReLU / LeakyReLU / smooth-L1 amplify to the per-mille level in single gradient
-    # elements (the fp64 yardstick of the same effect: tests/test_hip_fp64_yardstick.py)
-    assert worst[0] <= 2e-2, f"largest relative gradient difference {worst}"
+    # elements (the fp64 yardstick of the same effect: tests/test_hip_fp64_yardstick.py).  The largest single element is
+    # a chaotic quantity (it moved from 1.6e-2 to 2.2e-2 at 384x1248 when the GroupNorm pivot rule changed in round 4,
+    # with both sides of this comparison on the new rule), so it is bounded loosely and the per-tensor L2 distance tightly.
+    assert worst[0] <= 5e-2, f"largest relative gradient difference {worst}"
+    assert worst_l2[0] <= 1e-2, f"largest relative L2 gradient difference {worst_l2}"
     for k in ("dres0.0.0.weight", "dres0.0.1.weight", "dres1.0.0.weight", "mapping_matrix.similarity1.conv0.weight"):
         rel_close(ga[k], gb[k], 5e-3, k)

@@ -233,7 +233,9 @@ int dispatch_c2(const float* x, const float* wp, float* y, int B, int Ci, int Co
         if constexpr ((COTS & 4) != 0) if (p.cot == 2) { C2_GO(2, 2, 8); }
         if constexpr ((COTS & 16) != 0) if (p.cot == 4) { C2_GO(4, 2, 8); }
     } else {
-        if constexpr ((COTS & 2) != 0) if (p.cot == 1) { if (c2_nt(cg, Ho, 8) >= 8) { C2_GO(1, 8, 4); } C2_GO(1, 4, 4); }
+        // (8 rows per wave at stride 2 would stage a 65 x 65 halo per channel: 17 prefetch registers per channel next to 128
+        //  accumulators spilled 237 registers into private memory -- the only such kernel of the 2-D family; 4 rows fit)
+        if constexpr ((COTS & 2) != 0) if (p.cot == 1) { if constexpr (STRIDE == 1) { if (c2_nt(cg, Ho, 8) >= 8) { C2_GO(1, 8, 4); } } C2_GO(1, 4, 4); }
         if constexpr ((COTS & 4) != 0) if (p.cot == 2) { if (c2_nt(cg, Ho, 4) >= 4) { C2_GO(2, 4, 4); } C2_GO(2, 2, 4); }
         if constexpr ((COTS & 8) != 0) if (p.cot == 3) { C2_GO(3, 2, 4); }
         if constexpr ((COTS & 16) != 0) if (p.cot == 4) { if (c2_nt(cg, Ho, 2) >= 2) { C2_GO(4, 2, 4); } C2_GO(4, 1, 4); }

@@ -156,6 +156,9 @@ extern "C" int ecm_context_weights_fwd(const float* lr, const float* hr, const f
                                        int w, int s, int variant, void* stream) {
     ECM_CHECK_ARG(lr && hr && W0 && W1 && W2 && W3 && out && scratch && B > 0 && h > 0 && w > 0 && s > 0);
     if (s % 2 != 0 || B > 65535 || variant < 0 || variant > 2) return ECM_EUNSUP;   // the reference exits on odd scale
+    // eight-related (variant 0): the reference's offset tables are hard-coded for scale 4 (matrix_generation, cmfsm.py:391-428,
+    // quirk Q3) and its forward fails with a shape error at any other scale -- there is nothing to be equal to, so refuse
+    if (variant == 0 && s != 4) return ECM_EUNSUP;
     if (scratch_bytes < ecm_weights9_scratch_bytes(B, h, w)) return ECM_ESCRATCH;
     hipStream_t st = ecm_stream(stream);
     float* A = static_cast<float*>(scratch);

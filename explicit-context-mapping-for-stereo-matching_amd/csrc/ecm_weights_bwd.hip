@@ -94,293 +94,9 @@ __device__ __forceinline__ float mlp_forward(const float* __restrict__ a, const 
     return o;
 }
 
-// Two workgroups per CU: the kernel wants ~330 registers, so this bound spills ~65 of them to scratch, but a second
-// resident workgroup hides the scalar-cache weight loads and the two barriers per neighbour that a lone wave per SIMD
-// cannot (measured at 576x960: 1.54 ms at one workgroup per CU without spills, 1.10 ms at two with).
-template <int VAR>
-__global__ __launch_bounds__(256, 2) void ecm_weights_bwd_kernel(
-    const float* __restrict__ A, const float* __restrict__ hr, const float* __restrict__ W0, const float* __restrict__ W1,
-    const float* __restrict__ W2, const float* __restrict__ W3, const float* __restrict__ wsaved,
-    const float* __restrict__ gw, float* __restrict__ ghr, float* __restrict__ gA9, float* __restrict__ partB, int B, int h,
-    int w, int s, int tiles_x) {
-    using NB = Nbr<VAR>;
-    constexpr int NN = NB::N;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                   // [NCY*ncx][ASTRIDE]
-    float* Uall = As + NCY * NCXMAX * ASTRIDE;          // [4 waves][64][UST]
-    float* Rs = Uall + 4 * 64 * UST;                    // [4 waves][16 cells][32]
-    const int H = h * s, W = w * s;
-    const size_t HW = (size_t)H * W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    float* U = Uall + wave * 64 * UST;
-    const int ncx = TX / s + 2, ncell = TX / s, rbs = H / TY;      // cells per tile row, 4-row blocks per image
-
-    // persistent accumulators (per wave): MFMA tiles + 8 per-lane sums for W3
-    f32x4 accW1[2], accW2, accOff[2], accHr[2][2];
-    float accW3[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        accW1[0][i] = accW1[1][i] = accW2[i] = accOff[0][i] = accOff[1][i] = 0.f;
-        accHr[0][0][i] = accHr[0][1][i] = accHr[1][0][i] = accHr[1][1][i] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) accW3[i] = 0.f;
-
-    const long long ntiles = (long long)B * rbs * tiles_x;
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tx = (int)(tile % tiles_x);
-        const int rb = (int)((tile / tiles_x) % rbs);
-        const int b = (int)(tile / ((long long)tiles_x * rbs));
-        const int X0 = tx * TX, Y0 = rb * TY;
-        const int cy = Y0 / s;                            // workgroup-uniform: s % 4 == 0
-        const int cx0 = X0 / s - 1, cy0 = cy - 1;
-        __syncthreads();
-        for (int e = tid; e < NCY * ncx * (CF / 4); e += 256) {
-            const int q = e % (CF / 4), cell = e / (CF / 4);
-            const int yy = cy0 + cell / ncx, xx = cx0 + cell % ncx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yy >= 0 && yy < h && xx >= 0 && xx < w)
-                v = reinterpret_cast<const float4*>(A + (((size_t)b * h + yy) * w + xx) * CF)[q];
-            *reinterpret_cast<float4*>(As + cell * ASTRIDE + q * 4) = v;
-        }
-        __syncthreads();
-        const int Y = Y0 + wave, X = X0 + lane;
-        const bool valid = X < W;                         // right-edge partial tiles: dead lanes carry zeros
-        const int Xc = valid ? X : W - 1;
-        const size_t pix = (size_t)Y * W + Xc;
-        const float* hp = hr + (size_t)b * CF * HW + pix;
-        const int cx = Xc / s, ry = Y - cy * s, rx = Xc - cx * s;
-
-        float Bv[CF];
-        {
-            float hv[CF];
-#pragma unroll
-            for (int c = 0; c < CF; ++c) hv[c] = hp[(size_t)c * HW];
-#pragma unroll
-            for (int j = 0; j < CF; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int c = 0; c < CF; ++c) acc = fmaf(W0[j * 66 + 32 + c], hv[c], acc);
-                Bv[j] = acc;
-            }
-        }
-        // gradient w.r.t. the logits
-        float gl[NN];
-        if (!NB::TIMES_LOGIT) {
-            // out = softmax(l): gl[n] = p[n] (g[n] - sum_m p[m] g[m]), p = saved output
-            float wv[NN], dot = 0.f;
-#pragma unroll
-            for (int n = 0; n < NN; ++n) {
-                wv[n] = wsaved[((size_t)b * NN + n) * HW + pix];
-                gl[n] = gw[((size_t)b * NN + n) * HW + pix];
-                dot = fmaf(wv[n], gl[n], dot);
-            }
-#pragma unroll
-            for (int n = 0; n < NN; ++n) gl[n] = valid ? wv[n] * (gl[n] - dot) : 0.f;
-        } else {
-            // out = softmax(l) * l: recompute the logits, then gl[m] = p[m] (g[m] (l[m] + 1) - sum_n g[n] p[n] l[n])
-            float lg[NN];
-#pragma unroll 1
-            for (int n = 0; n < NN; ++n) {
-                const int yy = cy + NB::dy(n), xx = cx + NB::dx(n);
-                float v = NB::PAD;
-                if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-                    float h0[CF], h1[16], h2[8];
-                    const float* a = As + ((yy - cy0) * ncx + (xx - cx0)) * ASTRIDE;
-                    v = mlp_forward(a, Bv, ecm_off_x(NB::tab(n), rx, s), ecm_off_y(NB::tab(n), ry, s), W0, W1, W2, W3, h0, h1, h2);
-                    if (NB::FINAL_ACT) v = leaky(v);
-                }
-                lg[n] = v;
-            }
-            float m = lg[0];
-#pragma unroll
-            for (int n = 1; n < NN; ++n) m = fmaxf(m, lg[n]);
-            float p[NN], sum = 0.f;
-#pragma unroll
-            for (int n = 0; n < NN; ++n) { p[n] = expf(lg[n] - m); sum += p[n]; }
-            const float inv = 1.f / sum;
-            float dot = 0.f;
-#pragma unroll
-            for (int n = 0; n < NN; ++n) {
-                p[n] *= inv;
-                gl[n] = gw[((size_t)b * NN + n) * HW + pix];
-                dot = fmaf(gl[n], p[n] * lg[n], dot);
-            }
-#pragma unroll
-            for (int n = 0; n < NN; ++n) {
-                float g = p[n] * (gl[n] * (lg[n] + 1.f) - dot);
-                if (NB::FINAL_ACT) g *= dleaky(lg[n]);                 // through the LeakyReLU after conv3
-                gl[n] = valid ? g : 0.f;
-            }
-        }
-        float gBv[CF];
-#pragma unroll
-        for (int j = 0; j < CF; ++j) gBv[j] = 0.f;
-
-#pragma unroll 1
-        for (int n = 0; n < NN; ++n) {
-            const int yy = cy + NB::dy(n);
-            if (yy < 0 || yy >= h) continue;              // workgroup-uniform (the 4 rows share one LR cell row)
-            const int xx = cx + NB::dx(n);
-            const bool inb = xx >= 0 && xx < w;
-            const float g = inb ? gl[n] : 0.f;            // out-of-image neighbours carry a constant: no gradient
-            const int tab = NB::tab(n);
-            const float ox = ecm_off_x(tab, rx, s), oy = ecm_off_y(tab, ry, s);
-            const int xcl = min(max(xx, cx0), cx0 + ncx - 1);
-            const float* a = As + ((yy - cy0) * ncx + (xcl - cx0)) * ASTRIDE;
-            float h0[CF], h1[16], h2[8];
-            (void)mlp_forward(a, Bv, ox, oy, W0, W1, W2, W3, h0, h1, h2);
-            // ---- backward chain -----------------------------------------------------------------------
-            float g2[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                accW3[i] = fmaf(g, h2[i], accW3[i]);
-                g2[i] = W3[i] * g * dleaky(h2[i]);
-            }
-            float g1[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc = fmaf(W2[i * 16 + j], g2[i], acc);
-                g1[j] = acc * dleaky(h1[j]);
-            }
-            // (1) gW1 += g1^T h0 over the wave's 64 pixels
-#pragma unroll
-            for (int j = 0; j < CF; j += 4) *reinterpret_cast<float4*>(U + lane * UST + j) = make_float4(h0[j], h0[j + 1], h0[j + 2], h0[j + 3]);
-#pragma unroll
-            for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(U + lane * UST + 32 + j) = make_float4(g1[j], g1[j + 1], g1[j + 2], g1[j + 3]);
-            wave_lds_sync();
-#pragma unroll 4
-            for (int k0 = 0; k0 < 64; k0 += 4) {
-                const float* up = U + (k0 + l4) * UST;
-                const float av = up[32 + l15];
-                accW1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, up[l15], accW1[0], 0, 0, 0);
-                accW1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, up[16 + l15], accW1[1], 0, 0, 0);
-            }
-            wave_lds_sync();
-            // g0 = (W1^T g1) * phi'(h0)   (overwrites h0)
-#pragma unroll
-            for (int c = 0; c < CF; ++c) {
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc = fmaf(W1[i * CF + c], g1[i], acc);
-                h0[c] = acc * dleaky(h0[c]);
-                gBv[c] += h0[c];
-            }
-            // (2) gW0[:,64:66] += g0^T [ox,oy];  cell sums of g0 -> gA9
-#pragma unroll
-            for (int j = 0; j < CF; j += 4) *reinterpret_cast<float4*>(U + lane * UST + j) = make_float4(h0[j], h0[j + 1], h0[j + 2], h0[j + 3]);
-            *reinterpret_cast<float2*>(U + lane * UST + 32) = make_float2(ox, oy);
-            wave_lds_sync();
-#pragma unroll 4
-            for (int k0 = 0; k0 < 64; k0 += 4) {
-                const float* up = U + (k0 + l4) * UST;
-                const float bvv = l15 < 2 ? up[32 + l15] : 0.f;
-                accOff[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[l15], bvv, accOff[0], 0, 0, 0);
-                accOff[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[16 + l15], bvv, accOff[1], 0, 0, 0);
-            }
-            {   // lane -> (cell = lane / s, channels j0 .. j0 + 32/s): sum the cell's s pixels of this row
-                const int cell = lane / s, nj = CF / s > 0 ? CF / s : 1, j0 = (lane % s) * nj;
-                float sum[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) sum[u] = 0.f;
-                if (j0 < CF) {
-                    for (int pp = 0; pp < s; ++pp)
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (u < nj) sum[u] += U[(cell * s + pp) * UST + j0 + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (u < nj) Rs[(wave * 16 + cell) * CF + j0 + u] = sum[u];
-                }
-            }
-            __syncthreads();
-            for (int e = tid; e < ncell * CF; e += 256) {     // sum the 4 rows of each cell in a fixed order
-                const int cell = e / CF, j = e - cell * CF;
-                const int cxs = X0 / s + cell;
-                if (cxs < w) {
-                    const float v = (Rs[(0 * 16 + cell) * CF + j] + Rs[(1 * 16 + cell) * CF + j]) +
-                                    (Rs[(2 * 16 + cell) * CF + j] + Rs[(3 * 16 + cell) * CF + j]);
-                    gA9[((((size_t)b * rbs + rb) * w + cxs) * NN + n) * CF + j] = v;
-                }
-            }
-            __syncthreads();
-            // (3) gW2 += g2^T h1
-#pragma unroll
-            for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(U + lane * UST + j) = make_float4(h1[j], h1[j + 1], h1[j + 2], h1[j + 3]);
-#pragma unroll
-            for (int j = 0; j < 8; j += 4) *reinterpret_cast<float4*>(U + lane * UST + 16 + j) = make_float4(g2[j], g2[j + 1], g2[j + 2], g2[j + 3]);
-            wave_lds_sync();
-#pragma unroll 4
-            for (int k0 = 0; k0 < 64; k0 += 4) {
-                const float* up = U + (k0 + l4) * UST;
-                const float av = l15 < 8 ? up[16 + l15] : 0.f;
-                accW2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, up[l15], accW2, 0, 0, 0);
-            }
-            wave_lds_sync();
-        }
-        // ---- per pixel: ghr = W0_hr^T gBv ; gW0_hr += gBv^T hv ------------------------------------------
-        float hv[CF];
-#pragma unroll
-        for (int c = 0; c < CF; ++c) hv[c] = valid ? hp[(size_t)c * HW] : 0.f;
-        if (valid) {
-            float* gp = ghr + (size_t)b * CF * HW + pix;
-#pragma unroll
-            for (int c = 0; c < CF; ++c) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < CF; ++j) acc = fmaf(W0[j * 66 + 32 + c], gBv[j], acc);
-                gp[(size_t)c * HW] = acc;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < CF; j += 4) *reinterpret_cast<float4*>(U + lane * UST + j) = make_float4(gBv[j], gBv[j + 1], gBv[j + 2], gBv[j + 3]);
-#pragma unroll
-        for (int hs = 0; hs < 2; ++hs) {
-#pragma unroll
-            for (int j = 0; j < 16; j += 4)
-                *reinterpret_cast<float4*>(U + lane * UST + 32 + j) = make_float4(hv[hs * 16 + j], hv[hs * 16 + j + 1], hv[hs * 16 + j + 2], hv[hs * 16 + j + 3]);
-            wave_lds_sync();
-#pragma unroll 4
-            for (int k0 = 0; k0 < 64; k0 += 4) {
-                const float* up = U + (k0 + l4) * UST;
-                const float bvv = up[32 + l15];
-                accHr[0][hs] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[l15], bvv, accHr[0][hs], 0, 0, 0);
-                accHr[1][hs] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[16 + l15], bvv, accHr[1][hs], 0, 0, 0);
-            }
-            wave_lds_sync();
-        }
-    }
-
-    // ---- workgroup partial: sum the 4 waves' accumulators in LDS, then one store per entry -----------------
-    __syncthreads();
-    float* P = Uall;                                     // [4 waves][PB_N] (fits: 4*1736 < 4*64*48)
-    float* pw = P + wave * PB_N;
-    // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = l4 * 4 + r;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int hs = 0; hs < 2; ++hs) pw[PB_HR + (mt * 16 + row) * 32 + hs * 16 + l15] = accHr[mt][hs][r];   // gW0[j][32+c]
-            if (l15 < 2) pw[PB_OFF + (mt * 16 + row) * 2 + l15] = accOff[mt][r];                                   // gW0[j][64+o]
-        }
-        pw[PB_W1 + row * 32 + l15] = accW1[0][r];
-        pw[PB_W1 + row * 32 + 16 + l15] = accW1[1][r];
-        if (row < 8) pw[PB_W2 + row * 16 + l15] = accW2[r];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float v = wave_sum(accW3[i]);
-        if (lane == 0) pw[PB_W3 + i] = v;
-    }
-    __syncthreads();
-    for (int e = tid; e < PB_N; e += 256)
-        partB[(size_t)blockIdx.x * PB_N + e] = (P[e] + P[PB_N + e]) + (P[2 * PB_N + e] + P[3 * PB_N + e]);
-}
+// (The round-2 form of kernel B -- one wave per 64-pixel row, for any s % 4 == 0 -- was removed in round 4: it was the
+// library's one kernel with a private segment, 260 B per lane = 65 spilled VGPRs, and no registered architecture has a
+// scale other than 4, 8 or 16.  tools/check_private_segment.py now fails the build if any kernel spills.)
 
 // Kernel C: per LR cell.  gA = sum_n sum_{row blocks of the source cell} gA9[rb, cell - d_n, n];
 // glr[c] = sum_j W0[j][c] gA[j];  per-workgroup partial of gW0_lr[j][c] = sum_cells gA[j] lr[c].
@@ -486,8 +202,8 @@ __global__ __launch_bounds__(256) void ecm_weights_bwd_reduce(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Round-3 form of kernel B for s in {4, 8, 16} (every registered architecture).  Same mathematics and the same partial /
-// gA9 layouts as ecm_weights_bwd_kernel above (kept for s = 32, 64), restructured around two measured defects of it:
+// Kernel B for s in {4, 8, 16} (every registered architecture; other scales are ECM_EUNSUP).  Same mathematics and partial /
+// gA9 layouts as the round-2 kernel it replaced, restructured around two measured defects of that one:
 //   * the compiler hoisted all 2,760 loop-invariant weight loads out of the neighbour loop and then spilled ~1,800 SGPRs
 //     into VGPR lanes -- 3,500 v_readlane (+ 500 s_nop for the hazards) against 2,200 FMA instructions in the kernel, and
 //     65 VGPRs in scratch memory on top.  Here every weight matrix is reached through a pointer the compiler cannot see
@@ -681,14 +397,24 @@ __global__ __launch_bounds__(256, 2) void ecm_weights_bwd_kernel_p(
         const bool valid = X < W;                         // right-edge partial tiles: dead lanes carry zeros
         const int Xc = valid ? X : W - 1;
         const size_t pix = (size_t)Y * W + Xc;
-        const float* hp = hr + (size_t)b * CF * HW + pix;
+        // hr / saved planes / gradient planes / ghr through buffer descriptors: ONE 32-bit lane offset (the pixel) and the
+        // channel as the instruction's scalar offset.  Plain pointers made the compiler keep a 64-bit address per channel
+        // alive from the loads at the head of the tile to the re-loads at its tail (~64 registers): that, not the neighbour
+        // loop, was what spilled 50 VGPRs to private memory in round 3.
+        const unsigned HWb = (unsigned)HW * 4u, pixb = (unsigned)pix * 4u;
+        const auto hr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hr + (size_t)b * CF * HW), 0, (unsigned)CF * HWb, 0x00020000);
+        const auto sv_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsaved + (size_t)b * NN * HW), 0, (unsigned)NN * HWb, 0x00020000);
+        const auto gw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gw + (size_t)b * NN * HW), 0, (unsigned)NN * HWb, 0x00020000);
+        auto ldb = [](decltype(hr_rs) rs, unsigned voff, unsigned soff) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
+        };
         const int cx = Xc / s, ry = Y - cy * s, rx = Xc - cx * s;
 
         f32x2 Bv[CF / 2];                                // Bv = W0_hr hv, as (even, odd) channel pairs
         {
             f32x2 hv[CF / 2];
 #pragma unroll
-            for (int c = 0; c < CF / 2; ++c) { hv[c].x = hp[(size_t)(2 * c) * HW]; hv[c].y = hp[(size_t)(2 * c + 1) * HW]; }
+            for (int c = 0; c < CF / 2; ++c) { hv[c].x = ldb(hr_rs, pixb, (unsigned)(2 * c) * HWb); hv[c].y = ldb(hr_rs, pixb, (unsigned)(2 * c + 1) * HWb); }
             dense_rows<CF, 66, 32>(W0g, hv, Bv);
         }
         // gradient w.r.t. the logits
@@ -697,8 +423,8 @@ __global__ __launch_bounds__(256, 2) void ecm_weights_bwd_kernel_p(
             float wv[NN], dot = 0.f;
 #pragma unroll
             for (int n = 0; n < NN; ++n) {
-                wv[n] = wsaved[((size_t)b * NN + n) * HW + pix];
-                gl[n] = gw[((size_t)b * NN + n) * HW + pix];
+                wv[n] = ldb(sv_rs, pixb, (unsigned)n * HWb);
+                gl[n] = ldb(gw_rs, pixb, (unsigned)n * HWb);
                 dot = fmaf(wv[n], gl[n], dot);
             }
 #pragma unroll
@@ -732,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void ecm_weights_bwd_kernel_p(
 #pragma unroll
             for (int n = 0; n < NN; ++n) {
                 p[n] *= inv;
-                gl[n] = gw[((size_t)b * NN + n) * HW + pix];
+                gl[n] = ldb(gw_rs, pixb, (unsigned)n * HWb);
                 dot = fmaf(gl[n], p[n] * lg[n], dot);
             }
 #pragma unroll
@@ -890,15 +616,17 @@ __global__ __launch_bounds__(256, 2) void ecm_weights_bwd_kernel_p(
         {
             f32x2 acc[CF / 2];                            // ghr = W0_hr^T gBv, rows of the transposed copy
             dense_rows<CF, CF, 0>(W0hrT, gBv, acc);
-            if (valid) {
-                float* gp = ghr + (size_t)b * CF * HW + pix;
+            const auto gh_rs = __builtin_amdgcn_make_buffer_rsrc(ghr + (size_t)b * CF * HW, 0, (unsigned)CF * HWb, 0x00020000);
+            const unsigned so = valid ? pixb : 0x80000000u;          // dead lanes: out of range, the store is dropped
 #pragma unroll
-                for (int c = 0; c < CF / 2; ++c) { gp[(size_t)(2 * c) * HW] = acc[c].x; gp[(size_t)(2 * c + 1) * HW] = acc[c].y; }
+            for (int c = 0; c < CF / 2; ++c) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[c].x), gh_rs, (int)so, (int)((unsigned)(2 * c) * HWb), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[c].y), gh_rs, (int)so, (int)((unsigned)(2 * c + 1) * HWb), 0);
             }
         }
         float hv[CF];
 #pragma unroll
-        for (int c = 0; c < CF; ++c) hv[c] = valid ? hp[(size_t)c * HW] : 0.f;
+        for (int c = 0; c < CF; ++c) hv[c] = ldb(hr_rs, valid ? pixb : 0x80000000u, (unsigned)c * HWb);     // dead lanes read 0
 #pragma unroll
         for (int j = 0; j < 16; j += 2) *reinterpret_cast<float4*>(U + lane * UST + 2 * j) = make_float4(gBv[j].x, gBv[j].y, gBv[j + 1].x, gBv[j + 1].y);
 #pragma unroll
@@ -964,7 +692,6 @@ inline BwdPlan plan(int B, int h, int w, int s, int nn) {
     return p;
 }
 
-constexpr int BWD_LDS_BYTES = (NCY * NCXMAX * ASTRIDE + 4 * 64 * UST + 4 * 16 * CF) * 4;
 constexpr int BWD_LDS_BYTES_P = (NCY * NCXMAX * ASTRIDE + 4 * 64 * UST) * 4;
 
 template <int VAR>
@@ -975,16 +702,11 @@ int launch_bwd(const float* lr, const float* hr, const float* W0, const float* W
     const long long cells = (long long)B * h * w;
     float* W0hrT = base + p.offWT;
     hipLaunchKernelGGL(bwd_lr_proj, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, lr, W0, A, W0hrT, B, h * w);
-    if (s <= 16) {                                       // 4, 8, 16: a cell's pixels inside one wave's 4 x 16 patch
+    {                                                    // s in {4, 8, 16}: a cell's pixels inside one wave's 4 x 16 patch
         const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(ecm_weights_bwd_kernel_p<VAR>), BWD_LDS_BYTES_P);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(ecm_weights_bwd_kernel_p<VAR>, dim3(p.nB), dim3(256), BWD_LDS_BYTES_P, st, A, hr, W0, W1, W2, W3, saved,
                            gout, ghr, gA9, partB, W0hrT, B, h, w, s, p.tiles_x);
-    } else {
-        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(ecm_weights_bwd_kernel<VAR>), BWD_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(ecm_weights_bwd_kernel<VAR>, dim3(p.nB), dim3(256), BWD_LDS_BYTES, st, A, hr, W0, W1, W2, W3, saved,
-                           gout, ghr, gA9, partB, B, h, w, s, p.tiles_x);
     }
     hipLaunchKernelGGL(ecm_weights_bwd_cells<VAR>, dim3(p.nC), dim3(128), 0, st, gA9, lr, W0, glr, partC, B, h, w, s);
     hipLaunchKernelGGL(ecm_weights_bwd_reduce, dim3((2760 + 31) / 32), dim3(256), 0, st, partB, p.nB, partC, p.nC, gW);
@@ -996,7 +718,7 @@ inline int planes_of(int variant) { return variant == 0 ? 9 : variant == 1 ? 5 :
 }  // namespace
 
 extern "C" long long ecm_context_weights_bwd_scratch_bytes(int B, int h, int w, int s, int variant) {
-    if (B <= 0 || h <= 0 || w <= 0 || s < 4 || s % 4 != 0 || s > 64 || variant < 0 || variant > 2) return 0;
+    if (B <= 0 || h <= 0 || w <= 0 || (s != 4 && s != 8 && s != 16) || variant < 0 || variant > 2 || (variant == 0 && s != 4)) return 0;
     return plan(B, h, w, s, planes_of(variant)).total * (long long)sizeof(float);
 }
 
@@ -1005,7 +727,8 @@ extern "C" int ecm_context_weights_bwd(const float* lr, const float* hr, const f
                                        float* gW, void* scratch, long long scratch_bytes, int B, int h, int w, int s,
                                        int variant, void* stream) {
     ECM_CHECK_ARG(lr && hr && W0 && W1 && W2 && W3 && out_saved && gout && glr && ghr && gW && scratch && B > 0 && h > 0 && w > 0);
-    if (s < 4 || s % 4 != 0 || s > 64 || variant < 0 || variant > 2) return ECM_EUNSUP;
+    if ((s != 4 && s != 8 && s != 16) || variant < 0 || variant > 2) return ECM_EUNSUP;    // the registered architectures' scales
+    if (variant == 0 && s != 4) return ECM_EUNSUP;                                         // see ecm_context_weights_fwd
     const BwdPlan p = plan(B, h, w, s, planes_of(variant));
     if (scratch_bytes < p.total * (long long)sizeof(float)) return ECM_ESCRATCH;
     float* base = static_cast<float*>(scratch);

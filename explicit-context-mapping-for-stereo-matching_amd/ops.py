@@ -236,6 +236,9 @@ class ECMWeights9(torch.autograd.Function):
             raise ValueError("odd scale between hr and lr features (the reference calls exit() here, cmfsm.py:448-449)")
         if Cc != 32 or hr.shape[1] != 32 or H != h * s or W != w * s:
             raise RuntimeError(f"ecm_weights9: unsupported shapes lr {tuple(lr.shape)} hr {tuple(hr.shape)}")
+        if s != 4:      # matrix_generation hard-codes scale 4 (cmfsm.py:392): the reference's forward fails in torch.cat otherwise
+            raise RuntimeError(f"eight_related_context_mapping exists at scale 4 only (got {s}): the reference's offset tables "
+                               "are 4 x 4 and its forward raises a shape error at any other scale")
         w9 = torch.empty(B, 9, H, W, device=lr.device, dtype=lr.dtype)
         nb = _lib.query("ecm_weights9_scratch_bytes", B, h, w)
         scratch = _scratch(nb, lr.device)
@@ -303,7 +306,7 @@ class ContextWeights(torch.autograd.Function):
         gW = torch.empty(2112 + 512 + 128 + 8, device=lr.device, dtype=lr.dtype)
         nb = _lib.query("ecm_context_weights_bwd_scratch_bytes", B, h, w, s, variant)
         if nb == 0:
-            raise RuntimeError(f"context_weights backward: unsupported scale {s} (needs s % 4 == 0)")
+            raise RuntimeError(f"context_weights backward: unsupported scale {s} (the registered architectures' scales are 4, 8, 16)")
         scratch = _scratch(nb, lr.device)
         _lib.call("ecm_context_weights_bwd", _p(lr), _p(hr), _p(W0), _p(W1), _p(W2), _p(W3), _p(out), _p(g), _p(glr),
                   _p(ghr), _p(gW), _p(scratch), C.c_longlong(nb), B, h, w, s, variant, _stream())

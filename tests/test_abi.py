@@ -95,3 +95,18 @@ def test_wino_asm_loads_not_read_early():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "2 kernels checked, 0 problems" in r.stdout
 
+
+
+def test_no_kernel_uses_private_scratch_memory():
+    """Every kernel of libecm_hip.so must have `.private_segment_fixed_size` 0 and no VGPR spills (tools/check_private_segment.py
+    reads the AMDGPU metadata of the gfx950 code objects): a spilling kernel needs scratch memory provisioned at dispatch --
+    round 2's one such kernel was the one that aborted -- and pays for every spilled access."""
+    import subprocess
+    import sys
+    so = os.path.join(ROOT, "explicit-context-mapping-for-stereo-matching_amd", "csrc", "libecm_hip.so")
+    tools = ("/opt/rocm/lib/llvm/bin/llvm-readelf", "/opt/rocm/lib/llvm/bin/llvm-objcopy", "/opt/rocm/lib/llvm/bin/clang-offload-bundler")
+    if not os.path.exists(so) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("needs the built library and the ROCm llvm binutils")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_private_segment.py"), so], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 with a private segment" in r.stdout

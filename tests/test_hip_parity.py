@@ -33,6 +33,14 @@ def close(a, b, rtol=1e-4, atol=1e-5):
     torch.testing.assert_close(a.detach().cpu(), b.detach().cpu(), rtol=rtol, atol=atol)
 
 
+def close_grad(a, b, rel=1e-4):
+    """Gradients that are SUMS over many pixels (summation order differs between the kernel and autograd): the stated
+    per-stage rtol 1e-4, with the absolute floor tied to the tensor's scale -- 1e-4 of its largest element (an element near
+    a zero crossing of a sum of O(1) terms cannot be held to 1e-4 of ITSELF by any fp32 evaluation)."""
+    a, b = a.detach().cpu(), b.detach().cpu()
+    torch.testing.assert_close(a, b, rtol=rel, atol=rel * float(b.abs().max()) + 1e-7)
+
+
 # ------------------------------------------------------------------ a1
 @pytest.mark.parametrize("B,C,h,w,D", [(1, 4, 5, 12, 6), (2, 8, 4, 24, 20), (1, 32, 8, 12, 48), (2, 32, 16, 60, 48),
                                        (1, 3, 7, 13, 5), (1, 2, 3, 1100, 9), (1, 2, 40, 64, 64)])
@@ -123,7 +131,12 @@ def test_ecm_weights_golden(ecm, cmfsm_sd):
 @pytest.mark.parametrize("B,h,w,s", [(1, 8, 12, 4), (2, 5, 33, 4), (1, 3, 5, 2), (1, 4, 20, 8)])
 def test_ecm_weights_vs_oracle(ecm, cmfsm_sd, B, h, w, s):
     if s != 4:
-        pytest.skip("oracle tables are the reference's hard-coded scale-4 ones (quirk Q3)")
+        # the reference's tables are hard-coded for scale 4 (quirk Q3) and its forward raises a shape error otherwise:
+        # the eight-related kernel refuses such a call instead of computing something nothing can be compared with
+        lr, hr = seeded("ew.lr", B, 32, h, w), seeded("ew.hr", B, 32, h * s, w * s)
+        with pytest.raises(RuntimeError, match="scale 4 only"):
+            ecm.ops.ecm_weights9(dev(lr), dev(hr), *[dev(t) for t in _mlp(cmfsm_sd)])
+        return
     lr, hr = seeded("ew.lr", B, 32, h, w), seeded("ew.hr", B, 32, h * s, w * s)
     w9 = ecm.ops.ecm_weights9(dev(lr), dev(hr), *[dev(t) for t in _mlp(cmfsm_sd)])
     close(w9, O.ecm_weights_eight(lr, hr, cmfsm_sd), 1e-4, 1e-6)
@@ -136,10 +149,10 @@ def test_ecm_weights_bwd_golden(ecm, cmfsm_sd):
     Ws = [dev(t).requires_grad_() for t in _mlp(cmfsm_sd)]
     w9 = ecm.ops.ecm_weights9(lr, hr, *Ws)
     (w9 * dev(seeded("g2.G", 1, 9, 12, 16))).sum().backward()
-    close(lr.grad, g["g_lr"], 1e-3, 1e-5)
-    close(hr.grad, g["g_hr"], 1e-3, 1e-5)
+    close_grad(lr.grad, g["g_lr"])
+    close_grad(hr.grad, g["g_hr"])
     for i in range(4):
-        close(Ws[i].grad, g[f"g_similarity1_conv{i}_weight"], 1e-3, 1e-5)
+        close_grad(Ws[i].grad, g[f"g_similarity1_conv{i}_weight"])
 
 
 @pytest.mark.parametrize("B,h,w", [(1, 8, 12), (2, 5, 33), (1, 3, 16)])
@@ -152,10 +165,10 @@ def test_ecm_weights_bwd_vs_oracle(ecm, cmfsm_sd, B, h, w):
     sd = {k: v.clone().requires_grad_() for k, v in cmfsm_sd.items() if k.startswith("mapping_matrix")}
     lc, hc = lr.clone().requires_grad_(), hr.clone().requires_grad_()
     (O.ecm_weights_eight(lc, hc, sd) * G).sum().backward()
-    close(lg.grad, lc.grad, 1e-3, 1e-5)
-    close(hg.grad, hc.grad, 1e-3, 1e-5)
+    close_grad(lg.grad, lc.grad)
+    close_grad(hg.grad, hc.grad)
     for i in range(4):
-        close(Ws[i].grad, sd[f"mapping_matrix.similarity1.conv{i}.weight"].grad, 1e-3, 1e-4)
+        close_grad(Ws[i].grad, sd[f"mapping_matrix.similarity1.conv{i}.weight"].grad)
 
 
 def test_ecm_module_tuple(ecm, cmfsm_sd):

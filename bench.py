@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--explicit-cost-volume", action="store_true",
                    help="run the reference's explicit op sequence (4-D concat volume + 64->32 Conv3d) instead of the collapsed 2-D form")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--launch-table", default="", help="write the second pass's per-(entry point, shape) device times to this JSON file")
     return ap.parse_args()
 
 
@@ -361,6 +362,19 @@ def main():
     torch.cuda.synchronize()
     timers = lib.disable_timers()
     breakdown = step_breakdown(timers, n_pass2)
+    if args.launch_table and rank == 0:
+        rows = {}
+        for name, evs in timers.items():
+            for s_, e_, a in evs:
+                r = rows.setdefault((name, a), [0, 0.0])
+                r[0] += 1
+                r[1] += s_.elapsed_time(e_)
+        table = [{"entry": k[0], "family": _family(k[0], k[1]), "int_args": list(k[1]), "launches_per_step": v[0] / n_pass2,
+                  "ms_per_step": v[1] / n_pass2, "avg_launch_ms": v[1] / v[0]} for k, v in rows.items()]
+        table.sort(key=lambda r: -r["ms_per_step"])
+        with open(args.launch_table, "w") as f:
+            json.dump({"note": "per (C-ABI entry point, integer arguments) device time of one training step; HIP events, "
+                               "weight gradients on the main stream", "steps": n_pass2, "rows": table}, f, indent=0)
     ops.enable_wgrad_overlap(overlap_was)
     ops.check_async_errors()                               # a GroupNorm cluster time-out during the timed steps is fatal
     last = step()                                          # outside the timed region: the result must be finite

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libecm_hip.so")
+LIB_PATH = os.environ.get("ECM_HIP_LIB") or os.path.join(_HERE, "csrc", "libecm_hip.so")    # ECM_HIP_LIB: an experiment build
 
 _P, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 

@@ -49,3 +49,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }   // nn.LeakyReLU default slope
+
+// Streaming 16-byte store of a result that nothing in THIS kernel reads again (non-temporal hint: `global_store_dwordx4 ... nt`).
+// Measured in round 4 on the GroupNorm kernels (profiles/r04_gn_store_policy.txt): 4-18 % faster launches with the hint on the
+// stores, nothing from hinting the loads; the line still stays in the XCD's L2 for the next kernel (MI355X_MICROARCH.md).
+__device__ __forceinline__ void ecm_st_stream(float* p, const float4& v) {
+#ifdef ECM_NO_STREAM_STORES
+    *reinterpret_cast<float4*>(p) = v;
+#else
+    typedef float f32x4_st __attribute__((ext_vector_type(4)));
+    f32x4_st t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4_st*>(p));
+#endif
+}
+

@@ -29,6 +29,10 @@ __device__ unsigned long long wino_prof[4 * 8];   // [wave][phase] cycles of one
 #define WN_T(i) do { } while (0)
 #endif
 
+#ifndef ECM_WINO_ST_AUX
+#define ECM_WINO_ST_AUX 0            // cache policy of the epilogue's stores (2 = nt); see profiles/r04_gn_store_policy.txt
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,7 +44,7 @@ struct WinoCfg {
     static constexpr int V_FLOATS = 16 * CIC * NP * TR * 32;
     static constexpr int U_FLOATS = 16 * KD * CIC * 32;
     static constexpr int STAGE_FLOATS = 2 * (V_FLOATS + U_FLOATS);
-    static constexpr int EPI_FLOATS = NPR * 4 * 2 * 32 * 32;         // epilogue exchange: T[q][4 i][2 b][32 co][32 t]
+    static constexpr int EPI_FLOATS = NPR * 4 * 2 * 32 * 32;         // epilogue exchange: T[q][4 i][32 co][32 t][2 b]
     static constexpr int LDS_FLOATS = STAGE_FLOATS > EPI_FLOATS ? STAGE_FLOATS : EPI_FLOATS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static_assert(CIC * NP * TR * 32 == 256, "one input patch per thread per chunk");
@@ -317,25 +321,33 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    WN_T(1);
 
     // ---- epilogue: Y = A^T M A.  Wave w owns frequency ROW i = w (xi = 4w + j), so the column half of the transform,
     // T[i][b] = sum_j M[i][j] A[j][b], is done in registers; only T (2 of 4 values) crosses the waves through LDS:
-    // Ts[q][4 i][2 b][32 co][32 t] for all (plane, tile row) pairs q at once -- ONE rendezvous -- then
+    // Ts[q][4 i][32 co][32 t][2 b] for all (plane, tile row) pairs q at once -- ONE rendezvous -- then
     // Y[a][b] = sum_i A^T[a][i] T[i][b].  The stores go through a buffer descriptor over this workgroup's 32 output channels:
     // positions outside the volume (and channels beyond Co) carry the out-of-range offset and are dropped by the hardware,
     // so the store loop has no branches.
     float* Ts = smem;
     const size_t DHWo = DHWi;                                // stride 1, pad 1: output volume == input volume
     const bool w_even = (W & 1) == 0;
+    // exchange image Ts[q][4 i][32 co][32 t][2 b]: the pair (b = 0, 1) of a (co, t) sits in one 8-byte slot, so a lane writes
+    // it with ONE ds_write_b64 and the reader fetches a frequency row's pair with one ds_read_b64 -- half the LDS
+    // instructions of the [b][co][t] image of rounds 2-3 (the phase profile of round 4 showed the epilogue's two LDS passes
+    // at 45-95 cycles per instruction with the CU's other workgroup in its main loop: instruction count, not bytes);
+    // 32 consecutive lanes touch 256 consecutive bytes on either side: conflict-free
+    typedef float f32x2e __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int q = 0; q < NPR; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = (i & 3) + 8 * (i >> 2) + 4 * half;
             const float m0 = acc[0][q][i], m1 = acc[1][q][i], m2 = acc[2][q][i], m3 = acc[3][q][i];
-            Ts[(((q * 4 + wave) * 2 + 0) * 32 + co) * 32 + l31] = m0 + m1 + m2;
-            Ts[(((q * 4 + wave) * 2 + 1) * 32 + co) * 32 + l31] = m1 - m2 - m3;
+            const f32x2e tb = {m0 + m1 + m2, m1 - m2 - m3};
+            *reinterpret_cast<f32x2e*>(Ts + ((((q * 4 + wave) * 32 + co) * 32 + l31) * 2)) = tb;
         }
+    WN_T(3);
     const int nco = Co - grp * 32 < 32 ? Co - grp * 32 : 32;
     const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y + ((size_t)b * Co + (size_t)grp * 32) * DHWo, 0,
                                                        (unsigned)nco * plane_bytes, 0x00020000);
@@ -374,26 +386,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes done + raw barrier (no need to drain VMEM)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    WN_T(4);
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int q = 0; q < NPR; ++q)
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {                     // 1024 (co, t) pairs per q: 4 per thread, t == l31 for all of them
             const int col = (tid >> 5) + 8 * e4;
-            float tv[4][2];
+            f32x2e tv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int bq = 0; bq < 2; ++bq) tv[i][bq] = Ts[(((q * 4 + i) * 2 + bq) * 32 + col) * 32 + l31];
-            float y00 = tv[0][0] + tv[1][0] + tv[2][0], y01 = tv[0][1] + tv[1][1] + tv[2][1];
-            float y10 = tv[1][0] - tv[2][0] - tv[3][0], y11 = tv[1][1] - tv[2][1] - tv[3][1];
+            for (int i = 0; i < 4; ++i) tv[i] = *reinterpret_cast<const f32x2e*>(Ts + ((((q * 4 + i) * 32 + col) * 32 + l31) * 2));
+            const f32x2e yr0 = tv[0] + tv[1] + tv[2], yr1 = tv[1] - tv[2] - tv[3];        // same order of additions as before
+            float y00 = yr0.x, y01 = yr0.y, y10 = yr1.x, y11 = yr1.y;
             if (addend) { y00 += ad[q][e4][0]; y01 += ad[q][e4][1]; y10 += ad[q][e4][2]; y11 += ad[q][e4][3]; }
             const unsigned choff = (unsigned)col * plane_bytes;          // channel beyond Co: >= num_records, dropped
             if (has_col1) {
                 u32x2 r0 = {__builtin_bit_cast(unsigned, y00), __builtin_bit_cast(unsigned, y01)};
                 u32x2 r1 = {__builtin_bit_cast(unsigned, y10), __builtin_bit_cast(unsigned, y11)};
-                __builtin_amdgcn_raw_buffer_store_b64(r0, yrs, yoff[q][0] + choff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(r1, yrs, yoff[q][1] + choff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(r0, yrs, yoff[q][0] + choff, 0, ECM_WINO_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(r1, yrs, yoff[q][1] + choff, 0, ECM_WINO_ST_AUX);
             } else {
                 const int n = n0 + (q % TR) * 32 + l31;
                 const bool two = 2 * (n % tiles_wt) + 1 < W;

@@ -33,8 +33,8 @@ __device__ __forceinline__ void emit_one(float* __restrict__ outL, float* __rest
     if (x + 1 < d) { l.y = 0.f; r.y = 0.f; }
     if (x + 2 < d) { l.z = 0.f; r.z = 0.f; }
     if (x + 3 < d) { l.w = 0.f; r.w = 0.f; }
-    *reinterpret_cast<float4*>(outL + (size_t)d * plane) = l;
-    *reinterpret_cast<float4*>(outR + (size_t)d * plane) = r;
+    ecm_st_stream(outL + (size_t)d * plane, l);
+    ecm_st_stream(outR + (size_t)d * plane, r);
 }
 
 // w % 4 == 0 (so a float4 never straddles a row) and hw % 4 == 0.

@@ -620,8 +620,11 @@ __global__ __launch_bounds__(256, 2) void ecm_weights_bwd_kernel_p(
             const unsigned so = valid ? pixb : 0x80000000u;          // dead lanes: out of range, the store is dropped
 #pragma unroll
             for (int c = 0; c < CF / 2; ++c) {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[c].x), gh_rs, (int)so, (int)((unsigned)(2 * c) * HWb), 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[c].y), gh_rs, (int)so, (int)((unsigned)(2 * c + 1) * HWb), 0);
+                // (through scalar copies: __builtin_bit_cast applied to an ext_vector ELEMENT lvalue, `acc[c].y`, was lowered by
+                //  this hipcc to element 0 -- both stores of a pair wrote acc[c].x; caught by the g2 fixture)
+                const float ax = acc[c].x, ay = acc[c].y;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ax), gh_rs, (int)so, (int)((unsigned)(2 * c) * HWb), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ay), gh_rs, (int)so, (int)((unsigned)(2 * c + 1) * HWb), 0);
             }
         }
         float hv[CF];

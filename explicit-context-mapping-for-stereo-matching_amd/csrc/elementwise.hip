@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void sum_n_kernel(const float* __restrict__ a,
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         if (N >= 3) { const float4 u = reinterpret_cast<const float4*>(c)[i]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
         if (N >= 4) { const float4 u = reinterpret_cast<const float4*>(d)[i]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-        reinterpret_cast<float4*>(out)[i] = v;
+        ecm_st_stream(out + (size_t)i * 4, v);
     }
     // tail (n % 4 elements) by the first threads of the grid
     const long long t = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x;

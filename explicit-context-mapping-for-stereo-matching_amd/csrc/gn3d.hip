@@ -305,14 +305,21 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const float* p, int nv4) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, nv4 > 0 ? nv4 * 16 : 0, 0x00020000);
 }
+// cache-policy bits of the streaming loads / stores (aux operand: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef ECM_GN_LD_AUX
+#define ECM_GN_LD_AUX 0
+#endif
+#ifndef ECM_GN_ST_AUX
+#define ECM_GN_ST_AUX 2          // nt: measured 4-18 % per launch (profiles/r04_gn_store_policy.txt); loads gain nothing
+#endif
 __device__ __forceinline__ float4 slice_ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, ECM_GN_LD_AUX);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 __device__ __forceinline__ void slice_st(__amdgpu_buffer_rsrc_t r, unsigned off, const float4& f) {
     u32x4 v;
     v.x = __float_as_uint(f.x); v.y = __float_as_uint(f.y); v.z = __float_as_uint(f.z); v.w = __float_as_uint(f.w);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, ECM_GN_ST_AUX);
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {

@@ -445,12 +445,12 @@ def _wino_pack_both(w, kd):
     return packed[:nf], (packed[nf:], w._version, w.data_ptr())
 
 
-def _wino_pack_fwd(ctx, x, w, kd):
-    """Forward layout of w; in a pass that will need the data gradient, also the backward layout (stored on ctx)."""
-    # (grad mode is always OFF inside autograd.Function.forward, so it cannot be the test; needs_input_grad is all-False under
-    # no_grad / in eval and True for exactly the layers whose backward will run the data-gradient kernel)
+def _wino_pack_fwd(ctx, x, w, kd, grad_mode):
+    """Forward layout of w; in a pass that will need the data gradient, also the backward layout (stored on ctx).
+    `grad_mode`: torch.is_grad_enabled() as the CALLER saw it -- inside autograd.Function.forward grad mode is always off, and
+    needs_input_grad reflects the inputs' requires_grad flags even under no_grad, so neither can tell an eval call."""
     ctx.packed_b = None
-    if ctx.needs_input_grad[0] and not _FROZEN_DEPTH and not torch.cuda.is_current_stream_capturing():
+    if grad_mode and ctx.needs_input_grad[0] and not _FROZEN_DEPTH and not torch.cuda.is_current_stream_capturing():
         pf, ctx.packed_b = _wino_pack_both(w, kd)
         return pf
     return _wino_pack(w, kd, False)
@@ -705,8 +705,9 @@ class Conv3dK3(torch.autograd.Function):
     """nn.Conv3d(k=3, pad=1, stride 1|2, bias=False) (cmfsm.py:52-57)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, fork=False):
+    def forward(ctx, x, w, stride, fork=False, grad_mode=True):
         _chk(x, w)
+        ctx.side_ok = w.is_contiguous()        # else the saved weight is a COPY and AccumulateGrad will re-lay the gradient out (see _on_side)
         x, w = _c(x), _c(w)
         ctx.set_materialize_grads(False)
         if _is_c1(w, stride):
@@ -714,7 +715,7 @@ class Conv3dK3(torch.autograd.Function):
             y = torch.empty(B, 1, D, H, W, device=x.device, dtype=x.dtype)
             _lib.call("ecm_conv3d_c1_fwd", _p(x), _p(w), _p(y), B, Ci, D, H, W, _stream())
         elif stride == 1 and _wino_ok(x):
-            y = _wino_run(x, _wino_pack_fwd(ctx, x, w, 3), w.shape[0], 3)
+            y = _wino_run(x, _wino_pack_fwd(ctx, x, w, 3, grad_mode), w.shape[0], 3)
         else:
             y = _conv_fwd(x, _pack_conv(w), w.shape[0], stride)
         ctx.save_for_backward(x, w)
@@ -725,7 +726,7 @@ class Conv3dK3(torch.autograd.Function):
     def backward(ctx, gy, gskip=None):
         x, w = ctx.saved_tensors
         if gy is None:                         # only the forked input was used downstream
-            return gskip, None, None, None
+            return gskip, None, None, None, None
         gy = _c(gy)
         Co, Ci = w.shape[0], w.shape[1]
         def wfn():
@@ -737,7 +738,7 @@ class Conv3dK3(torch.autograd.Function):
                 _lib.call("ecm_conv3d_c1_wgrad", _p(x), _p(gy), _p(g), _p(scratch), C.c_longlong(nb), B, Ci, D, H, W,
                           _stream())
                 return g
-            return _wgrad(x, gy, Co, Ci, ctx.stride, w)
+            return _wgrad(x, gy, Co, Ci, ctx.stride, w if ctx.side_ok else None)
 
         def dfn():
             if ctx.stride == 1 and _wino_ok(x) and not _is_c1(w, ctx.stride):
@@ -752,7 +753,7 @@ class Conv3dK3(torch.autograd.Function):
                 g = _deconv_fwd(gy, _pack_deconv(w), Ci, x.shape[2:])
             return _fork_grad(g, gskip)
         gx, gw = _launch_pair(wfn if ctx.needs_input_grad[1] else None, dfn if ctx.needs_input_grad[0] else None)
-        return gx, gw, None, None
+        return gx, gw, None, None, None
 
 
 def _is_c1(w, stride):
@@ -865,7 +866,7 @@ class Conv2dG(torch.autograd.Function):
     same kernel on flipped / transposed weights; stride 2: the transposed-conv kernel) and weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, dil, pad_top, pad_left, Ho, Wo, fork=False):
+    def forward(ctx, x, w, stride, dil, pad_top, pad_left, Ho, Wo, fork=False, grad_mode=True):
         _chk(x, w)
         x = _c(x)
         ctx.set_materialize_grads(False)
@@ -876,7 +877,7 @@ class Conv2dG(torch.autograd.Function):
         ctx.wino_f, ctx.wino_b = _wino_ok(x) and same and Ci >= WINO2D_MIN_CI, _wino_ok(x) and same and Co >= WINO2D_MIN_CI
         ctx.wino_same = same
         if ctx.wino_f:
-            y = _wino_run(x, _wino_pack_fwd(ctx, x, _c(w), 1), Co, 1)
+            y = _wino_run(x, _wino_pack_fwd(ctx, x, _c(w), 1, grad_mode), Co, 1)
         else:
             y = _conv2d_run(x, _pack2d(w, False), Co, kh, kw, stride, dil, pad_top, pad_left, Ho, Wo)
         ctx.save_for_backward(x, w)
@@ -887,7 +888,7 @@ class Conv2dG(torch.autograd.Function):
     def backward(ctx, gy, gskip=None):
         x, w = ctx.saved_tensors
         if gy is None:
-            return (gskip,) + (None,) * 8
+            return (gskip,) + (None,) * 9
         stride, dil, pad_top, pad_left, Ho, Wo = ctx.cfg
         Co, Ci, kh, kw = w.shape
         B, _, H, W = x.shape
@@ -931,7 +932,7 @@ class Conv2dG(torch.autograd.Function):
                 _lib.call("ecm_zero_insert2d", _p(small), _p(g), C.c_longlong(B * Ci), H, W, Ho, Wo, _stream())
             return _fork_grad(g, gskip)
         gx, gw = _launch_pair(wfn if ctx.needs_input_grad[1] else None, dfn if ctx.needs_input_grad[0] else None)
-        return gx, gw, None, None, None, None, None, None, None
+        return gx, gw, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, stride=1, dil=1, pad_top=None, pad_left=None, Ho=None, Wo=None, fork=False):
@@ -945,7 +946,7 @@ def conv2d(x, w, stride=1, dil=1, pad_top=None, pad_left=None, Ho=None, Wo=None,
         Ho = (H + 2 * pt - dil * (kh - 1) - 1) // stride + 1
     if Wo is None:
         Wo = (W + 2 * pl - dil * (kw - 1) - 1) // stride + 1
-    return Conv2dG.apply(x, w, int(stride), int(dil), pt, pl, int(Ho), int(Wo), bool(fork))
+    return Conv2dG.apply(x, w, int(stride), int(dil), pt, pl, int(Ho), int(Wo), bool(fork), torch.is_grad_enabled())
 
 
 def conv2d_k3(x, w):
@@ -974,31 +975,32 @@ class Conv2dPlanes(torch.autograd.Function):
     the Winograd kernels: forward, data gradient and weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, fork=False):
+    def forward(ctx, x, w, fork=False, grad_mode=True):
         _chk(x, w)
+        ctx.side_ok = w.is_contiguous()
         x, w = _c(x), _c(w)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, w)
-        return _fork_out(_wino_run(x, _wino_pack_fwd(ctx, x, w, 1), w.shape[0], 1), x, fork)
+        return _fork_out(_wino_run(x, _wino_pack_fwd(ctx, x, w, 1, grad_mode), w.shape[0], 1), x, fork)
 
     @staticmethod
     def backward(ctx, gy, gskip=None):
         x, w = ctx.saved_tensors
         if gy is None:
-            return gskip, None, None
+            return gskip, None, None, None
         gy = _c(gy)
-        gx, gw = _launch_pair((lambda: _wino_wgrad(x, gy, w.shape[0], w.shape[1], 1, w)) if ctx.needs_input_grad[1] else None,
+        gx, gw = _launch_pair((lambda: _wino_wgrad(x, gy, w.shape[0], w.shape[1], 1, w if ctx.side_ok else None)) if ctx.needs_input_grad[1] else None,
                               (lambda: _wino_run(gy, _wino_pack_b(ctx, w, 1), w.shape[1], 1, addend=gskip)) if ctx.needs_input_grad[0] else None)
-        return gx, gw, None
+        return gx, gw, None, None
 
 
 def conv2d_planes(x, w, fork=False):
-    return Conv2dPlanes.apply(x, w, bool(fork))
+    return Conv2dPlanes.apply(x, w, bool(fork), torch.is_grad_enabled())
 
 
 def conv3d_k3(x, w, stride=1, fork=False):
     """fork=True: returns (y, x') with x' a view of x to be used as the skip operand (see _fork_out)."""
-    return Conv3dK3.apply(x, w, int(stride), bool(fork))
+    return Conv3dK3.apply(x, w, int(stride), bool(fork), torch.is_grad_enabled())
 
 
 class Deconv3dK3S2(torch.autograd.Function):
@@ -1007,6 +1009,7 @@ class Deconv3dK3S2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         _chk(x, w)
+        ctx.side_ok = w.is_contiguous()
         x, w = _c(x), _c(w)
         B, Ci, D, H, W = x.shape
         y = _deconv_fwd(x, _pack_deconv(w), w.shape[1], (2 * D, 2 * H, 2 * W))
@@ -1020,7 +1023,7 @@ class Deconv3dK3S2(torch.autograd.Function):
         Ci, Co = w.shape[0], w.shape[1]
         # gw[ci,co,k] = sum x[ci,i] gy[co,2i+k-1]: the conv-wgrad with x:=gy (big), gy:=x, "Co":=Ci, "Ci":=Co
         # gx[ci,i] = sum_{co,k} gy[co,2i+k-1] w[ci,co,k]: a stride-2 conv with w read as Conv3d [Cout=Ci,Cin=Co]
-        gx, gw = _launch_pair((lambda: _wgrad(gy, x, Ci, Co, 2, w)) if ctx.needs_input_grad[1] else None,
+        gx, gw = _launch_pair((lambda: _wgrad(gy, x, Ci, Co, 2, w if ctx.side_ok else None)) if ctx.needs_input_grad[1] else None,
                               (lambda: _conv_fwd(gy, _pack_conv(w), Ci, 2)) if ctx.needs_input_grad[0] else None)
         return gx, gw
 

@@ -30,7 +30,8 @@ int main(int argc, char** argv) {
     }
     unsigned long long prof[32];
     (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(wino_prof), sizeof(prof));
-    const char* names[6] = {"setup + prologue", "-", "main loop (MFMA groups with staging slices, rendezvous)", "-", "-", "epilogue"};
+    const char* names[6] = {"setup + prologue", "drain + rendezvous before the epilogue", "main loop (MFMA groups with staging slices, rendezvous)",
+                            "epilogue: column transform + exchange writes", "epilogue: offsets, addend loads, rendezvous", "epilogue: exchange reads, row transform, stores"};
     for (int w = 0; w < 4; w += 3) {
         unsigned long long tot = 0; for (int i = 0; i < 6; ++i) tot += prof[w * 8 + i];
         printf("wave %d total %llu cycles\n", w, tot);

@@ -155,39 +155,49 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     };
     // V = B^T d B of the patch in `raw` -> Vs image `dst`: 16 frequency planes, this thread's (pc, pz, pr, t) slot.
     // Two halves so that each fits into the shadow of one group of MFMAs in the main loop.
-    float tmp[16];
-    auto transform_rows = [&](const f32x2 (&rawp)[8]) {
-        float raw[16];
+    // The transform in packed fp32 arithmetic (v_pk_add_f32: two adds per instruction): a patch row arrives as two 8-byte
+    // pairs, which ARE the even-aligned register pairs the packed instructions want, so the row pass B^T d is 8 packed
+    // instructions instead of 16 scalar ones; the column pass (.) B mixes the halves of a pair and is written so that each
+    // output pair is one packed add with half-select / negate modifiers.  (Instruction issue next to the MFMAs is what bounds
+    // this kernel: DESIGN.md section 3.)
+    f32x2 tmp[8];                                            // tmp[2 i], tmp[2 i + 1] = columns (0,1), (2,3) of row i of B^T d
+    auto rows_pass = [&](const f32x2 (&r)[8]) {              // rows: B^T d, on column pairs
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            raw[i * 4 + 0] = rawp[i * 2].x; raw[i * 4 + 1] = rawp[i * 2].y;
-            raw[i * 4 + 2] = rawp[i * 2 + 1].x; raw[i * 4 + 3] = rawp[i * 2 + 1].y;
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 d0 = r[h], d1 = r[2 + h], d2 = r[4 + h], d3 = r[6 + h];
+            tmp[h] = d0 - d2; tmp[2 + h] = d1 + d2; tmp[4 + h] = d2 - d1; tmp[6 + h] = d1 - d3;
         }
+    };
+    auto transform_rows = [&](const f32x2 (&rawp)[8]) {
         if (wg_edge) {                                       // pairs read shifted at a row end: move into place, zero the pad
+            f32x2 raw[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float a0 = raw[i * 4], a1 = raw[i * 4 + 1], b0 = raw[i * 4 + 2], b1 = raw[i * 4 + 3];
-                raw[i * 4 + 0] = edge_l ? 0.f : a0;
-                raw[i * 4 + 1] = edge_l ? a0 : a1;
-                raw[i * 4 + 2] = edge_r ? b1 : b0;
-                raw[i * 4 + 3] = edge_r ? 0.f : b1;
+                const float a0 = rawp[i * 2].x, a1 = rawp[i * 2].y, b0 = rawp[i * 2 + 1].x, b1 = rawp[i * 2 + 1].y;
+                raw[i * 2].x = edge_l ? 0.f : a0;
+                raw[i * 2].y = edge_l ? a0 : a1;
+                raw[i * 2 + 1].x = edge_r ? b1 : b0;
+                raw[i * 2 + 1].y = edge_r ? 0.f : b1;
             }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                        // rows: B^T d
-            const float d0 = raw[j], d1 = raw[4 + j], d2 = raw[8 + j], d3 = raw[12 + j];
-            tmp[j] = d0 - d2; tmp[4 + j] = d1 + d2; tmp[8 + j] = d2 - d1; tmp[12 + j] = d1 - d3;
+            rows_pass(raw);
+        } else {
+            rows_pass(rawp);                                 // (straight from the load registers: no copies)
         }
     };
     auto transform_cols_store = [&](float* dst) {
         float* vp = dst + ((pc * NP + pz) * TR + pr) * 32 + l31;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                        // columns: (.) B
-            const float e0 = tmp[i * 4], e1 = tmp[i * 4 + 1], e2 = tmp[i * 4 + 2], e3 = tmp[i * 4 + 3];
-            vp[(i * 4 + 0) * (CIC * NP * TR * 32)] = e0 - e2;
-            vp[(i * 4 + 1) * (CIC * NP * TR * 32)] = e1 + e2;
-            vp[(i * 4 + 2) * (CIC * NP * TR * 32)] = e2 - e1;
-            vp[(i * 4 + 3) * (CIC * NP * TR * 32)] = e1 - e3;
+            const f32x2 A = tmp[i * 2], Bq = tmp[i * 2 + 1];     // (e0, e1), (e2, e3)
+            f32x2 o01, o23;
+            // (e0 - e2, e1 + e2): low = A.lo - B.lo, high = A.hi + B.lo;   (e2 - e1, e1 - e3): low = -A.hi + B.lo, high = A.hi - B.hi
+            // (hipcc lowers the same expressions to scalar adds plus register-pair moves: spelled out)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(o01) : "v"(A), "v"(Bq));
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(o23) : "v"(A), "v"(Bq));
+            vp[(i * 4 + 0) * (CIC * NP * TR * 32)] = o01.x;
+            vp[(i * 4 + 1) * (CIC * NP * TR * 32)] = o01.y;
+            vp[(i * 4 + 2) * (CIC * NP * TR * 32)] = o23.x;
+            vp[(i * 4 + 3) * (CIC * NP * TR * 32)] = o23.y;
         }
     };
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wino|wgrad|wino_wgrad|gn|ecmw_bwd|costvol] [B]"""
+"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wino|wino2d|wino2d64|wino2d128|wgrad|wino_wgrad|gn|ecmw_bwd|costvol] [B]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +16,11 @@ elif which == "wino":
     x = torch.randn(B, 32, 48, 144, 240, device=dev); w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
     pk = ops._wino_pack(w, 3, False)
     for _ in range(5): y = ops._wino_run(x, pk, 32, 3)
+elif which in ("wino2d", "wino2d64", "wino2d128"):
+    Cc, H, W = {"wino2d": (32, 576, 960), "wino2d64": (64, 144, 240), "wino2d128": (128, 144, 240)}[which]
+    x = torch.randn(B, Cc, H, W, device=dev); w = torch.randn(Cc, Cc, 3, 3, device=dev) * 0.05
+    pk = ops._wino_pack(w, 1, False)
+    for _ in range(5): y = ops._wino_run(x, pk, Cc, 1)
 elif which == "wino_wgrad":
     x = torch.randn(B, 32, 48, 144, 240, device=dev); gy = torch.randn(B, 32, 48, 144, 240, device=dev)
     for _ in range(5): g = ops._wino_wgrad(x, gy, 32, 32, 3)

@@ -141,6 +141,11 @@ def disable_timers():
     return out
 
 
+class _Args(tuple):
+    """The integer arguments of a timed launch (what bench.py indexes); `.longs` holds the 64-bit ones (sizes) beside them."""
+    longs = ()
+
+
 def call(name: str, *args):
     """Call an int-returning entry point and raise RuntimeError on a non-zero code."""
     lib = load()
@@ -156,7 +161,9 @@ def call(name: str, *args):
         s.record()
         rc = fn(*args)
         e.record()
-        rec.append((s, e, tuple(a for a in args if isinstance(a, int))))
+        ints = _Args(a for a in args if isinstance(a, int))
+        ints.longs = tuple(a.value for a in args if isinstance(a, C.c_longlong))
+        rec.append((s, e, ints))
     else:
         rc = fn(*args)
     if rc != 0:

@@ -201,13 +201,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
         }
     };
 
+    // No zero fill: the first MFMA into each accumulator (chunk 0, kk = 0, kd = 0) takes a constant-zero C operand -- an inline
+    // constant of the instruction -- instead of 16 v_mov per accumulator (128 VALU instructions per wave in the prologue of a
+    // kernel whose non-matrix instructions cost matrix-pipe time by their count).
     f32x16 acc[4][NPR];
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int q = 0; q < NPR; ++q)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[f][q][i] = 0.f;
 
 #ifdef WINO_PROFILE
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = clock64();
@@ -264,8 +261,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     //   group 3: operands of group 1 of chunk c+1; patch loads of chunk c+3 into the registers just transformed
     // No wave overwrites what another may still read: every read of V/U[c] is issued before the rendezvous of chunk c (and
     // complete at it: lgkmcnt(0)); V[c+2] and U[c+2] are written after it.
-    auto chunk_body = [&](int c, f32x2 (&raw_next)[8], auto is_last) {
+    auto chunk_body = [&](int c, f32x2 (&raw_next)[8], auto is_last, auto is_first) {
         constexpr bool LAST = decltype(is_last)::value;         // the odd chunk out at the end: nothing left to stage
+        constexpr bool FIRST = decltype(is_first)::value;       // chunk 0: the accumulators start from the constant 0
         const int buf = c & 1;
         const bool more = !LAST && c + 1 < nchunks;
 #pragma unroll
@@ -277,9 +275,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
 #pragma unroll
                     for (int p = 0; p < TD; ++p)
 #pragma unroll
-                        for (int r = 0; r < TR; ++r)
-                            acc[f][p * TR + r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[f][kk][kd], bw[f][kk][p + kd][r],
-                                                                                      acc[f][p * TR + r], 0, 0, 0);
+                        for (int r = 0; r < TR; ++r) {
+                            const f32x16 zero = {};
+                            acc[f][p * TR + r] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                av[f][kk][kd], bw[f][kk][p + kd][r], (FIRST && kk == 0 && kd == 0) ? zero : acc[f][p * TR + r], 0, 0, 0);
+                        }
             if (f == 0) {
                 read_ops(buf, 2);
                 // chunk c+1's patch, loaded two chunks ago; younger: weights of c+1, patch of c+2.  Waited for even when it
@@ -315,11 +315,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     };
     {
         int c = 0;
-        for (; c + 1 < nchunks; c += 2) {
-            chunk_body(c, rawB, std::false_type{});          // chunk c even: chunk c+1's patch is in rawB
-            chunk_body(c + 1, rawA, std::false_type{});
+        if (nchunks >= 2) {                                  // the first pair, peeled: chunk 0 starts the accumulators
+            chunk_body(0, rawB, std::false_type{}, std::true_type{});
+            chunk_body(1, rawA, std::false_type{}, std::false_type{});
+            c = 2;
+            for (; c + 1 < nchunks; c += 2) {
+                chunk_body(c, rawB, std::false_type{}, std::false_type{});          // chunk c even: chunk c+1's patch is in rawB
+                chunk_body(c + 1, rawA, std::false_type{}, std::false_type{});
+            }
+            if (c < nchunks) chunk_body(c, rawB, std::true_type{}, std::false_type{});
+        } else {
+            chunk_body(0, rawB, std::true_type{}, std::true_type{});              // a single chunk: first and last
         }
-        if (c < nchunks) chunk_body(c, rawB, std::true_type{});
     }
     // Before the epilogue reuses the staging buffers: (1) this wave's VMEM queue drained -- the weight DMA issued past the
     // last chunk still WRITES LDS when it lands, and the patch loads issued past the last chunk (empty descriptor) still

@@ -85,12 +85,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     // offset (hardware zero fill).  A pair never straddles the end of a row: at the left border pair A is read one column to
     // the right, at the right border pair B one column to the left, and transform_rows moves the values into place.
     unsigned poff[8];
+#ifdef ECM_WINO_ALIAS       // timing experiment only (results invalid): every workgroup reads the SAME 64 tiles -> cache-resident input
+    const int n_t = (pr * 32 + l31) + 0 * n0;
+#else
     const int n_t = n0 + pr * 32 + l31;                      // this thread's tile; past the last one: everything out of range
+#endif
     const int trow_t = n_t / tiles_wt;
     const int oh_t = 2 * trow_t, ow_t = n_t < ntile ? 2 * (n_t - trow_t * tiles_wt) : W;   // first output row / column
     const bool edge_l = ow_t == 0, edge_r = ow_t + 2 >= W && ow_t + 1 < W;
     {
+#ifdef ECM_WINO_ALIAS
+        const int gz = (KD == 3 ? 1 : 0) + pz - KD / 2 + 0 * od0;
+#else
         const int gz = od0 - KD / 2 + pz;
+#endif
         const int gy0 = oh_t - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -102,7 +110,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
         }
     }
     const bool wg_edge = __builtin_amdgcn_ballot_w64(edge_l || edge_r) != 0;   // some tile of this wave touches a row end
+#ifdef ECM_WINO_ALIAS
+    const float* xb = x;
+#else
     const float* xb = x + (size_t)b * Ci * DHWi;
+#endif
     const unsigned plane_bytes = (unsigned)DHWi * 4u;
     const int pc_u = __builtin_amdgcn_readfirstlane(pc);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -238,9 +250,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     wait_raw(rawA, std::integral_constant<int, NUQ + 8>{});   // younger than chunk 0's patch: its weights, chunk 1's patch
     transform_rows(rawA);
     transform_cols_store(Vs);
+    load_raw(2, rawA);                                       // (issue order as in the main loop: patch c+2, then weights c+1)
     dma_u(last_chunk < 1 ? last_chunk : 1, Us + UF);
-    load_raw(2, rawA);
-    // weights of chunk 0 landed: younger are chunk 1's patch, chunk 1's weights and chunk 2's patch
+    // weights of chunk 0 landed: younger are chunk 1's patch, chunk 2's patch and chunk 1's weights
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 + NUQ) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // raw barrier: see the main loop
     __builtin_amdgcn_s_barrier();
@@ -254,11 +266,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     // small enough to issue in the group's shadow; the operands of a group are read from LDS TWO groups ahead, so neither
     // their latency nor the rendezvous below is on the critical path of the matrix pipe -- a wave keeps its pipe fed even
     // while the other workgroup of the CU is in its prologue / epilogue:
-    //   group 0: operands of group 2; transform chunk c+1's patch (loaded two chunks ago) into the other V buffer
+    //   group 0: operands of group 2; transform chunk c+1's patch (loaded two chunks ago) into the other V buffer, then the
+    //            patch loads of chunk c+3 into the registers just transformed
     //   group 1: operands of group 3; wait for chunk c+1's weights (DMA issued a chunk ago) and meet the other waves -- the
     //            ONLY rendezvous per chunk, taken while every wave still has half a chunk of MFMAs to issue
     //   group 2: operands of group 0 of chunk c+1; weight DMA of chunk c+2 into the U buffer just vacated
-    //   group 3: operands of group 1 of chunk c+1; patch loads of chunk c+3 into the registers just transformed
+    //   group 3: operands of group 1 of chunk c+1
     // No wave overwrites what another may still read: every read of V/U[c] is issued before the rendezvous of chunk c (and
     // complete at it: lgkmcnt(0)); V[c+2] and U[c+2] are written after it.
     auto chunk_body = [&](int c, f32x2 (&raw_next)[8], auto is_last, auto is_first) {
@@ -282,18 +295,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
                         }
             if (f == 0) {
                 read_ops(buf, 2);
-                // chunk c+1's patch, loaded two chunks ago; younger: weights of c+1, patch of c+2.  Waited for even when it
-                // is past the end and unused: until then its registers must not be handed to anything else.
-                wait_raw(raw_next, std::integral_constant<int, NUQ + 8>{});
+                // chunk c+1's patch, loaded two chunks ago; younger: weights of c, patch of c+2, weights of c+1 (chunk 0: patch
+                // of c+2 and weights of c+1 only).  Waited for even when it is past the end and unused: until then its
+                // registers must not be handed to anything else.
+                wait_raw(raw_next, std::integral_constant<int, (FIRST ? NUQ : 2 * NUQ) + 8>{});
                 if (more) {
                     transform_rows(raw_next);
                     transform_cols_store(Vs + (buf ^ 1) * VF);
                 }
+                // Round 4: the registers just transformed get chunk c+3's patch HERE, not at the end of the chunk -- the loads
+                // then have two whole chunks to land instead of 1.25 (the patch is the kernel's only HBM-latency-bound
+                // operand: with 8 chunks of ~2,400 cycles the old window was ~1.4 us)
+                if (!LAST) load_raw(c + 3, raw_next);
             }
             if (f == 1) {
                 read_ops(buf, 3);
                 if (!LAST) {
-                    // chunk c+1's weights landed: the only VMEM operations younger than their DMA are chunk c+2's 8 patch loads.
+                    // chunk c+1's weights landed: the only VMEM operations younger than their DMA are chunk c+3's 8 patch loads.
                     // NOT __syncthreads(): its fence waits vmcnt(0), i.e. for those loads too -- a memory round trip per chunk
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -307,7 +325,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
             }
             if (f == 3 && !LAST) {
                 if (more) read_ops(buf ^ 1, 1);
-                load_raw(c + 3, raw_next);                                 // the registers just transformed get chunk c+3's patch
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -250,9 +250,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     wait_raw(rawA, std::integral_constant<int, NUQ + 8>{});   // younger than chunk 0's patch: its weights, chunk 1's patch
     transform_rows(rawA);
     transform_cols_store(Vs);
-    load_raw(2, rawA);                                       // (issue order as in the main loop: patch c+2, then weights c+1)
     dma_u(last_chunk < 1 ? last_chunk : 1, Us + UF);
-    // weights of chunk 0 landed: younger are chunk 1's patch, chunk 2's patch and chunk 1's weights
+    load_raw(2, rawA);
+    // weights of chunk 0 landed: younger are chunk 1's patch, chunk 1's weights and chunk 2's patch
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 + NUQ) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // raw barrier: see the main loop
     __builtin_amdgcn_s_barrier();
@@ -266,12 +266,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
     // small enough to issue in the group's shadow; the operands of a group are read from LDS TWO groups ahead, so neither
     // their latency nor the rendezvous below is on the critical path of the matrix pipe -- a wave keeps its pipe fed even
     // while the other workgroup of the CU is in its prologue / epilogue:
-    //   group 0: operands of group 2; transform chunk c+1's patch (loaded two chunks ago) into the other V buffer, then the
-    //            patch loads of chunk c+3 into the registers just transformed
+    //   group 0: operands of group 2; transform chunk c+1's patch (loaded two chunks ago) into the other V buffer
     //   group 1: operands of group 3; wait for chunk c+1's weights (DMA issued a chunk ago) and meet the other waves -- the
     //            ONLY rendezvous per chunk, taken while every wave still has half a chunk of MFMAs to issue
     //   group 2: operands of group 0 of chunk c+1; weight DMA of chunk c+2 into the U buffer just vacated
-    //   group 3: operands of group 1 of chunk c+1
+    //   group 3: operands of group 1 of chunk c+1; patch loads of chunk c+3 into the registers just transformed
     // No wave overwrites what another may still read: every read of V/U[c] is issued before the rendezvous of chunk c (and
     // complete at it: lgkmcnt(0)); V[c+2] and U[c+2] are written after it.
     auto chunk_body = [&](int c, f32x2 (&raw_next)[8], auto is_last, auto is_first) {
@@ -293,29 +292,31 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
                             acc[f][p * TR + r] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                                 av[f][kk][kd], bw[f][kk][p + kd][r], (FIRST && kk == 0 && kd == 0) ? zero : acc[f][p * TR + r], 0, 0, 0);
                         }
+#ifdef ECM_WINO_ABLATE_OPREADS
+#define read_ops(a, b) do { } while (0)
+#endif
             if (f == 0) {
                 read_ops(buf, 2);
-                // chunk c+1's patch, loaded two chunks ago; younger: weights of c, patch of c+2, weights of c+1 (chunk 0: patch
-                // of c+2 and weights of c+1 only).  Waited for even when it is past the end and unused: until then its
-                // registers must not be handed to anything else.
-                wait_raw(raw_next, std::integral_constant<int, (FIRST ? NUQ : 2 * NUQ) + 8>{});
+                // chunk c+1's patch, loaded two chunks ago; younger: weights of c+1, patch of c+2.  Waited for even when it
+                // is past the end and unused: until then its registers must not be handed to anything else.
+                wait_raw(raw_next, std::integral_constant<int, NUQ + 8>{});
+#ifndef ECM_WINO_ABLATE_TRANSFORM
                 if (more) {
                     transform_rows(raw_next);
                     transform_cols_store(Vs + (buf ^ 1) * VF);
                 }
-                // Round 4: the registers just transformed get chunk c+3's patch HERE, not at the end of the chunk -- the loads
-                // then have two whole chunks to land instead of 1.25 (the patch is the kernel's only HBM-latency-bound
-                // operand: with 8 chunks of ~2,400 cycles the old window was ~1.4 us)
-                if (!LAST) load_raw(c + 3, raw_next);
+#endif
             }
             if (f == 1) {
                 read_ops(buf, 3);
                 if (!LAST) {
-                    // chunk c+1's weights landed: the only VMEM operations younger than their DMA are chunk c+3's 8 patch loads.
+                    // chunk c+1's weights landed: the only VMEM operations younger than their DMA are chunk c+2's 8 patch loads.
                     // NOT __syncthreads(): its fence waits vmcnt(0), i.e. for those loads too -- a memory round trip per chunk
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef ECM_WINO_ABLATE_BARRIER     // timing experiments only (results invalid): tools/experiments/README.md, round 4
                     __builtin_amdgcn_s_barrier();
+#endif
                     asm volatile("" ::: "memory");
                 }
             }
@@ -325,9 +326,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_mfma(const float* __restrict
             }
             if (f == 3 && !LAST) {
                 if (more) read_ops(buf ^ 1, 1);
+                // the registers just transformed get chunk c+3's patch.  (Round 4 tried issuing these loads in group 0, right
+                // behind the transform -- a two-chunk window instead of 1.25 chunks: 1-2 % SLOWER on every layer; with the
+                // input made cache-resident the kernel gains 3 % (3-D) to 11 % (2-D 32 -> 32), so memory latency is not
+                // what it mostly waits for.  tools/experiments/README.md)
+                load_raw(c + 3, raw_next);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef ECM_WINO_ABLATE_OPREADS
+#undef read_ops
+#endif
         WN_T(2);
     };
     {

@@ -177,7 +177,16 @@ def launch_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this host driver
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))     # rank 0 prints the line
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+
+    def relay(stream):
+        # rank 0's stdout: the JSON line goes to stdout, anything a library prints there (gloo's connection banner) to stderr
+        for line in stream:
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+    import threading
+    pump = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    pump.start()
     worst, failed_at = 0, None
     while any(p.poll() is None for p in procs):
         time.sleep(0.2)
@@ -196,6 +205,7 @@ def launch_ranks(args):
     for p in procs:
         rc = p.wait()
         worst = worst or (rc if rc > 0 else (128 - rc if rc < 0 else 0))
+    pump.join(timeout=10)
     sys.exit(worst)
 
 

@@ -324,7 +324,7 @@ def main():
         if not args.graph:
             ops.frozen_weights().__enter__()          # fixed weights for the whole run: pack each layer's weights once
         if args.graph:
-            graphed = ecm_dist.GraphedForward(model, left, right)
+            graphed = ecm_dist.GraphedForward(model, left, right, cluster_groupnorm=True)    # one graph, replayed alone
 
             def step():
                 return graphed(left, right)[2]

@@ -712,7 +712,7 @@ extern "C" int ecm_gn3d_apply(const float* x, const float* mean_rstd, const floa
 namespace {
 
 // ---- process-wide control of the cluster kernels ---------------------------------------------------------------------
-// mode: 1 = cluster kernels with ticket assignment (default), 0 = two-stage kernels only (no inter-workgroup waits at
+// mode: 1 = cluster kernels with ticket assignment (default; 4 = the same, ALSO on a stream under graph capture), 0 = two-stage kernels only (no inter-workgroup waits at
 // all), 2 = cluster kernels with static member ids and 3 = a deliberately undersized grid (both diagnostics: 3 makes
 // every cluster time out so the error path can be tested).  Env ECM_GN_CLUSTER_MODE / ECM_GN_POLL_MS preset them.
 struct GnControl {
@@ -785,10 +785,14 @@ inline FusedLaunch fused_prepare(float* scratch, bool preset, int B, int C, long
     if (mode == 3 && L.g.cl == 1) return L;
     {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        bool capturing = false;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
-        else if (cs != hipStreamCaptureStatusNone) return L;        // captured: two-stage kernels (see GnControl)
+        else capturing = cs != hipStreamCaptureStatusNone;
+        // captured: two-stage kernels (see GnControl) -- unless the caller has promised, with mode 4, that graphs holding cluster
+        // launches are never replayed concurrently with each other or with eager GroupNorm work (no ordering can be recorded)
+        if (capturing && mode != 4) return L;
         int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < GnControl::MAX_DEV) {      // (launch_mu is held by the caller)
+        if (!capturing && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < GnControl::MAX_DEV) {   // (launch_mu is held by the caller)
             if (c.have_last[dev] && c.last_stream[dev] != st) {
                 if (!c.multi[dev]) {
                     c.multi[dev] = true;
@@ -823,6 +827,9 @@ inline FusedLaunch fused_prepare(float* scratch, bool preset, int B, int C, long
 // behind a cluster launch (launch_mu held): in multi-stream mode, the event the next launch on another stream waits for
 inline void fused_launched(hipStream_t st) {
     GnControl& c = gn_ctl();
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cs != hipStreamCaptureStatusNone) return;           // (mode 4: a captured cluster launch takes no part in the ordering)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GnControl::MAX_DEV || !c.multi[dev]) return;
     if (!c.order_ev[dev]) {                                 // creation failed earlier: fall back to draining the device
@@ -879,7 +886,7 @@ extern "C" int ecm_gn3d_cluster_mode(int mode) {
     std::lock_guard<std::mutex> lock(c.mu);
     c.env_read = true;                       // an explicit call overrides the environment preset
     const int old = c.mode;
-    if (mode >= 0 && mode <= 3) c.mode = mode;
+    if (mode >= 0 && mode <= 4) c.mode = mode;
     return old;
 }
 

@@ -240,7 +240,12 @@ class GraphedForward:
     `load_state_dict` into the same model.  Inputs are copied into the graph's static buffers; the returned tensors are
     the graph's static outputs (valid until the next call).  Shapes are fixed at construction."""
 
-    def __init__(self, model: torch.nn.Module, left: torch.Tensor, right: torch.Tensor, warmup: int = 3):
+    def __init__(self, model: torch.nn.Module, left: torch.Tensor, right: torch.Tensor, warmup: int = 3,
+                 cluster_groupnorm: bool = False):
+        """`cluster_groupnorm`: capture the one-pass (cluster) GroupNorm kernels instead of the two-stage ones a capturing
+        stream gets by default.  One read pass less per GroupNorm; only for a graph that is never replayed concurrently with
+        another graph or with eager GroupNorm work on another stream (two cluster launches in flight together starve each
+        other: csrc/gn3d.hip, GnControl)."""
         assert left.is_cuda and right.is_cuda, "GraphedForward captures a HIP graph: GPU tensors only"
         self.model = model.eval()
         self.left, self.right = left.clone(), right.clone()
@@ -252,8 +257,14 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.out = self.model(self.left, self.right)
+        from . import ops
+        old = ops.gn_cluster_mode(4) if cluster_groupnorm else None      # matters at capture time only: which kernels are recorded
+        try:
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.out = self.model(self.left, self.right)
+        finally:
+            if old is not None:
+                ops.gn_cluster_mode(old)
 
     def __call__(self, left: torch.Tensor, right: torch.Tensor):
         self.left.copy_(left)

@@ -236,7 +236,11 @@ int ecm_gn3d_apply(const float* x, const float* mean_rstd, const float* gamma, c
  * -- call it after synchronising the stream at the end of a step.  Never a hang, never a silent success.
  *   ecm_gn3d_cluster_mode(mode): 1 = cluster kernels (default), 0 = two-stage kernels only (no inter-workgroup waits:
  *     the safe choice when many processes share one device), 2 / 3 = diagnostics (static member ids / undersized grid that
- *     forces the timeout path); any other value only queries.  Returns the previous mode.  Env ECM_GN_CLUSTER_MODE presets it.
+ *     forces the timeout path), 4 = as 1, and ALSO on a stream that is being captured into a HIP graph (by default a capturing
+ *     stream gets the two-stage kernels: two graphs with cluster launches replayed concurrently would starve each other, and
+ *     cluster launches of one process are otherwise ordered across streams by the library -- mode 4 is the caller's promise
+ *     that such graphs replay one at a time); any other value only queries.  Returns the previous mode.  Env
+ *     ECM_GN_CLUSTER_MODE presets it.
  *   ecm_gn3d_poll_ms(ms): wait bound in milliseconds (default 2000; ms <= 0 only queries).  Returns the previous bound. */
 int ecm_gn3d_cluster_mode(int mode);
 int ecm_gn3d_poll_ms(int ms);

@@ -156,6 +156,15 @@ def test_graphed_forward_matches_eager(ecm):
         want = hot(a, b)
     for x, y in zip(got, want):
         assert float((x - y).abs().max()) <= 2e-2 and float((x - y).abs().mean()) <= 1e-3
+    # a graph that will be replayed alone may keep the cluster kernels (ecm_gn3d_cluster_mode 4 during capture): then it
+    # equals the eager default bit for bit, and the process-wide mode is back to what it was
+    before = ecm.ops.gn_cluster_mode(-1)
+    gc = dist.GraphedForward(hot, *feats(), cluster_groupnorm=True)
+    assert ecm.ops.gn_cluster_mode(-1) == before
+    got = [t.clone() for t in gc(a, b)]
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+    ecm.ops.check_async_errors()
 
     l0, r0 = (torch.randn(1, 3, 256, 512, device="cuda", generator=g) for _ in range(2))
     gf = dist.GraphedForward(model, l0, r0)

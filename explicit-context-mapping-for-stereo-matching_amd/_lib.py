@@ -55,6 +55,8 @@ PROTOTYPES = {
     "ecm_conv3d_c1_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ecm_conv3d_c1_wgrad_scratch_bytes": (_LL, [_I, _I, _I, _I, _I]),
     "ecm_conv3d_c1_wgrad": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
+    "ecm_conv3d_c1_gn_fwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _I, _P]),
+    "ecm_conv3d_c1_gn_wgrad": (_I, [_P] * 7 + [_LL, _I, _I, _I, _I, _I, _P]),
     "ecm_deconv3d_pack_weight": (_I, [_P, _P, _I, _I, _P]),
     "ecm_deconv3d_k3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ecm_conv3d_wgrad_scratch_bytes": (_LL, [_I, _I, _I, _I, _I, _I, _I]),

@@ -1,5 +1,5 @@
 #include "common.h"
-extern "C" int ecm_abi_version(void) { return 3; }
+extern "C" int ecm_abi_version(void) { return 4; }
 extern "C" const char* ecm_error_string(int code) {
     switch (code) {
         case 0: return "success";

@@ -37,9 +37,17 @@ constexpr int V_LDS_BYTES = (V_X_FLOATS + V_W_FLOATS + 2) * 4;   // + the scratc
 static_assert(2 * V_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 __device__ __forceinline__ int v_slot(int dz, int hy, int wx) { return ((dz * VH_H + hy) * VROW + wx + 2 * ((hy >> 1) & 1)) * 2; }
 
+// GN = true (round 4): x is the RAW output of the classifier's first convolution and the kernel applies GroupNorm(32) + ReLU
+// (cmfsm.py:621-634: convbn_3d -> ReLU -> Conv3d 32 -> 1) while it stages the halo tile: h = max(fma(x, a_c, sh_c), 0) with
+// a_c = rstd * gamma_c, sh_c = fma(-mean, a_c, beta_c) -- the expression of gn3d.hip's gn_affine, so h has the bits the
+// stand-alone GroupNorm kernel would have written -- and positions outside the volume stay 0 (the convolution pads h, not x).
+// The normalised tensor (849 MB per head at batch 4) is then never written or read: one read pass of x for the statistics
+// (ecm_gn3d_stats) replaces the GroupNorm kernel's read + write.  Ci == 32 only (one channel per group).
+template <bool GN>
 __global__ __launch_bounds__(256, 2) void conv3d_c1_fwd_v(const float* __restrict__ x, const float* __restrict__ w,
                                                           float* __restrict__ y, int Ci, int D, int H, int W, int tiles_d,
-                                                          int tiles_h, int tiles_w) {
+                                                          int tiles_h, int tiles_w, const float* __restrict__ mean_rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [VH_D][VH_H][VROW][2]
     float* Ws = smem + V_X_FLOATS;          // [pair][27][2]
@@ -100,6 +108,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_c1_fwd_v(const float* __restric
     char* xs_c = reinterpret_cast<char*>(Xs);
     for (int pair = 0; pair < npairs; ++pair) {
         if (pair > 0) __syncthreads();                       // everyone has finished with the previous pair's tile
+        if (GN) {
+            // one channel per group (Ci == 32): group = channel; coefficients are wave-uniform
+            const int c0 = 2 * pair;
+            const float m0 = mean_rstd[(b * 32 + c0) * 2], r0 = mean_rstd[(b * 32 + c0) * 2 + 1];
+            const float m1 = mean_rstd[(b * 32 + c0 + 1) * 2], r1 = mean_rstd[(b * 32 + c0 + 1) * 2 + 1];
+            const float a0 = r0 * gamma[c0], a1 = r1 * gamma[c0 + 1];
+            const float s0 = __builtin_fmaf(-m0, a0, beta[c0]), s1 = __builtin_fmaf(-m1, a1, beta[c0 + 1]);
+#pragma unroll
+            for (int k = 0; k < VSLOTS; ++k) {
+                const bool in = goff[k] != 0x80000000u;
+                rr[k].x = in ? fmaxf(__builtin_fmaf(rr[k].x, a0, s0), 0.f) : 0.f;
+                rr[k].y = in ? fmaxf(__builtin_fmaf(rr[k].y, a1, s1), 0.f) : 0.f;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < VSLOTS; ++k) *reinterpret_cast<f32x2*>(xs_c + lslot[k]) = rr[k];
         __syncthreads();
@@ -343,9 +365,13 @@ constexpr int G_GYF = (GTD + 2) * GPS;                                   //   =>
 constexpr int G_LDS_BYTES = (32 * GXSTR + G_GYF) * 4;                   // 71 KB: two workgroups per CU
 static_assert((GTH + 2) * GRS <= GPS, "plane stride too small");
 
+// GN = true: x is the raw conv output, normalised + ReLU'd on its way into LDS as in conv3d_c1_fwd_v<true> (positions outside the
+// volume stay 0: they pair with in-volume gy values of the halo).
+template <bool GN>
 __global__ __launch_bounds__(256) void conv3d_c1_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
                                                        float* __restrict__ partial, int B, int Ci, int D, int H, int W,
-                                                       int tiles_d, int tiles_h, int tiles_w) {
+                                                       int tiles_d, int tiles_h, int tiles_w, const float* __restrict__ mean_rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [32 ci][GXSTR]
     float* Gs = smem + 32 * GXSTR;          // gy halo tile [(GTD+2)][GPS] (rows of GRS)
@@ -369,6 +395,8 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad(const float* __restrict__
     constexpr int NGH = (GTD + 2) * (GTH + 2) * (GTW + 2);                 // gy halo elements
     constexpr int PG = (NGH + 255) / 256;
     float xr[64], gr[PG];
+    bool xin[2] = {false, false};                                         // GN: is the prefetched x position inside the volume?
+    int xb_next = 0;                                                      // GN: sample index of the prefetched tile
     int gdst[PG];                                                         // tile-invariant LDS slot of each halo element
 #pragma unroll
     for (int j = 0; j < PG; ++j) {
@@ -393,7 +421,9 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad(const float* __restrict__
             const int gz = d0 + dz, gyy = h0 + hy, gx = w0 + xx;
             const bool ok = live && gz < D && gyy < H && gx < W;
             off[j] = ok ? (unsigned)(gz * (int)HW + gyy * W + gx) * 4u : 0x80000000u;
+            if (GN) xin[j] = ok;
         }
+        if (GN) xb_next = b;
         const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * Ci * DHW), 0,
                                                            (unsigned)nci * xplane, 0x00020000);
 #pragma unroll
@@ -416,6 +446,15 @@ __global__ __launch_bounds__(256) void conv3d_c1_wgrad(const float* __restrict__
     prefetch(blockIdx.x);
     for (unsigned tile = blockIdx.x; tile < (unsigned)ntiles; tile += gridDim.x) {
         __syncthreads();
+        if (GN) {
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) {
+                const float m = mean_rstd[(xb_next * 32 + cc) * 2], r = mean_rstd[(xb_next * 32 + cc) * 2 + 1];
+                const float a = r * gamma[cc], sh = __builtin_fmaf(-m, a, beta[cc]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xr[cc * 2 + j] = xin[j] ? fmaxf(__builtin_fmaf(xr[cc * 2 + j], a, sh), 0.f) : 0.f;
+            }
+        }
 #pragma unroll
         for (int cc = 0; cc < 32; ++cc)
 #pragma unroll
@@ -491,20 +530,33 @@ inline long long c1_tiles(int B, int D, int H, int W) {
 
 }  // namespace
 
+namespace {
+template <bool GN>
+int launch_c1_fwd_v(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, const float* mean_rstd,
+                    const float* gamma, const float* beta, void* stream) {
+    const int td = (D + VT_D - 1) / VT_D, th = (H + VT_H - 1) / VT_H, tw = (W + VT_W - 1) / VT_W;
+    const long long nb = (long long)B * td * th * tw;
+    if (nb > 0x7fffffffLL) return ECM_EUNSUP;
+    const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(conv3d_c1_fwd_v<GN>), V_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv3d_c1_fwd_v<GN>, dim3((unsigned)nb), dim3(256), V_LDS_BYTES, ecm_stream(stream), x, w, y, Ci, D, H, W, td,
+                       th, tw, mean_rstd, gamma, beta);
+    return ECM_LAUNCH_RESULT();
+}
+}  // namespace
+
+extern "C" int ecm_conv3d_c1_gn_fwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* w,
+                                    float* y, int B, int Ci, int D, int H, int W, void* stream) {
+    ECM_CHECK_ARG(x && mean_rstd && gamma && beta && w && y && B > 0 && D > 0 && H > 0 && W > 0);
+    if (Ci != 32 || (long long)D * H * W * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;      // one channel per GroupNorm group
+    return launch_c1_fwd_v<true>(x, w, y, B, Ci, D, H, W, mean_rstd, gamma, beta, stream);
+}
+
 extern "C" int ecm_conv3d_c1_fwd(const float* x, const float* w, float* y, int B, int Ci, int D, int H, int W, void* stream) {
     ECM_CHECK_ARG(x && w && y && B > 0 && Ci > 0 && D > 0 && H > 0 && W > 0);
     if (Ci > 32 || (long long)D * H * W * 4 * 32 >= 0x7fffffffLL) return ECM_EUNSUP;
     static const bool valu = [] { const char* v = getenv("ECM_C1_VALU"); return !(v && v[0] == '0'); }();
-    if (valu && Ci % 2 == 0) {
-        const int td = (D + VT_D - 1) / VT_D, th = (H + VT_H - 1) / VT_H, tw = (W + VT_W - 1) / VT_W;
-        const long long nb = (long long)B * td * th * tw;
-        if (nb > 0x7fffffffLL) return ECM_EUNSUP;
-        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(conv3d_c1_fwd_v), V_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(conv3d_c1_fwd_v, dim3((unsigned)nb), dim3(256), V_LDS_BYTES, ecm_stream(stream), x, w, y, Ci, D, H, W, td, th,
-                           tw);
-        return ECM_LAUNCH_RESULT();
-    }
+    if (valu && Ci % 2 == 0) return launch_c1_fwd_v<false>(x, w, y, B, Ci, D, H, W, nullptr, nullptr, nullptr, stream);
     const int tiles_h = (H + MTH - 1) / MTH, tiles_w = (W + MTW - 1) / MTW;
     // split the disparity axis only as far as needed to give the chip ~3 rounds of workgroups (each chunk re-reads 2 planes)
     const long long cols = (long long)B * tiles_h * tiles_w;
@@ -539,22 +591,38 @@ extern "C" long long ecm_conv3d_c1_wgrad_scratch_bytes(int B, int Ci, int D, int
     return (long long)c1_workers(c1_tiles(B, D, H, W)) * Ci * 27 * (long long)sizeof(float);
 }
 
-extern "C" int ecm_conv3d_c1_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B,
-                                   int Ci, int D, int H, int W, void* stream) {
-    ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && D > 0 && H > 0 && W > 0);
+namespace {
+template <bool GN>
+int launch_c1_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B, int Ci, int D, int H,
+                    int W, const float* mean_rstd, const float* gamma, const float* beta, void* stream) {
     if (Ci > 32 || (long long)D * H * W * 4 * 32 >= 0x7fffffffLL || c1_tiles(B, D, H, W) >= 0x7fffffffLL) return ECM_EUNSUP;
     if (scratch_bytes < ecm_conv3d_c1_wgrad_scratch_bytes(B, Ci, D, H, W)) return ECM_ESCRATCH;
     const int tiles_d = (D + GTD - 1) / GTD, tiles_h = (H + GTH - 1) / GTH, tiles_w = (W + GTW - 1) / GTW;
     const int P = c1_workers(c1_tiles(B, D, H, W));
     hipStream_t st = ecm_stream(stream);
     {
-        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(conv3d_c1_wgrad), G_LDS_BYTES);
+        const hipError_t e = ecm_allow_lds(reinterpret_cast<const void*>(conv3d_c1_wgrad<GN>), G_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
     }
     float* partial = static_cast<float*>(scratch);
-    hipLaunchKernelGGL(conv3d_c1_wgrad, dim3(P), dim3(256), G_LDS_BYTES, st, x, gy, partial, B, Ci, D, H, W, tiles_d, tiles_h,
-                       tiles_w);
+    hipLaunchKernelGGL(conv3d_c1_wgrad<GN>, dim3(P), dim3(256), G_LDS_BYTES, st, x, gy, partial, B, Ci, D, H, W, tiles_d, tiles_h,
+                       tiles_w, mean_rstd, gamma, beta);
     const int n = Ci * 27;
     hipLaunchKernelGGL(c1_wgrad_reduce, dim3((n + 31) / 32), dim3(256), 0, st, partial, gw, n, P);
     return ECM_LAUNCH_RESULT();
+}
+}  // namespace
+
+extern "C" int ecm_conv3d_c1_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes, int B,
+                                   int Ci, int D, int H, int W, void* stream) {
+    ECM_CHECK_ARG(x && gy && gw && scratch && B > 0 && Ci > 0 && D > 0 && H > 0 && W > 0);
+    return launch_c1_wgrad<false>(x, gy, gw, scratch, scratch_bytes, B, Ci, D, H, W, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int ecm_conv3d_c1_gn_wgrad(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* gy,
+                                      float* gw, void* scratch, long long scratch_bytes, int B, int Ci, int D, int H, int W,
+                                      void* stream) {
+    ECM_CHECK_ARG(x && mean_rstd && gamma && beta && gy && gw && scratch && B > 0 && D > 0 && H > 0 && W > 0);
+    if (Ci != 32) return ECM_EUNSUP;
+    return launch_c1_wgrad<true>(x, gy, gw, scratch, scratch_bytes, B, Ci, D, H, W, mean_rstd, gamma, beta, stream);
 }

@@ -171,6 +171,26 @@ def _cbn(seq, x, skip=None, relu=False, fork=False):
     return seq[1].fused(seq[0](x), skip, relu)
 
 
+# The tail of a classifier -- GroupNorm + ReLU + Conv3d(32 -> 1), cmfsm.py:621-634 -- as ONE op that never writes the
+# normalised tensor (ops.classifier_tail).  ECM_C1_GN_FUSE=0 / models.C1_GN_FUSE = False: the three stages separately.
+C1_GN_FUSE = _os.environ.get("ECM_C1_GN_FUSE", "1") != "0"
+
+
+def _classifier(clf, x, fork=False):
+    """clf = Sequential(convbn_3d(32, 32), ReLU, Conv3d(32, 1)).  -> raw logits [B,D,h,w] (and, with fork, x for the other
+    consumer of the classifier's input, cf. _cbn)."""
+    conv, gn, last = clf[0][0], clf[0][1], clf[2]
+    if fork:
+        y, xs = conv(x, fork=True)
+    else:
+        y, xs = conv(x), None
+    if C1_GN_FUSE and y.is_cuda and tuple(last.weight.shape) == (1, 32, 3, 3, 3):
+        out = ops.classifier_tail(y, gn.weight, gn.bias, last.weight).squeeze(1)
+    else:
+        out = last(gn.fused(y, None, True)).squeeze(1)
+    return (out, xs) if fork else out
+
+
 # ------------------------------------------------------------------------------------------------
 # encoder (cmfsm.py:61-85, 126-236)
 # ------------------------------------------------------------------------------------------------
@@ -484,13 +504,12 @@ class cmfsm(nn.Module):
         c_in, c_r1, c_r2, c_r3 = ops.fork(cost0, 4)
         # pre1 has four consumers (two inside dres2, the skips of dres3 and dres4): one 4-ary gradient sum
         out1, (pre1a, pre1b), post1 = self.dres2(c_in, None, None, residual=c_r1, pre_uses=2)   # :686-687
-        h1, out1 = _cbn(self.classif1[0], out1, relu=True, fork=True)                  # :695
+        c1, out1 = _classifier(self.classif1, out1, fork=True)                         # :695
         out2, pre2, post2 = self.dres3(out1, pre1a, post1, residual=c_r2)              # :689-690
-        h2, out2 = _cbn(self.classif2[0], out2, relu=True, fork=True)                  # :724
+        c2, out2 = _classifier(self.classif2, out2, fork=True)                         # :724
         out3, pre3, post3 = self.dres4(out2, pre1b, post2, residual=c_r3)              # :692-693
-        h3 = _cbn(self.classif3[0], out3, relu=True)                                   # :747
-        heads = [clf[2](h).squeeze(1) for clf, h in ((self.classif1, h1), (self.classif2, h2), (self.classif3, h3))]
-        disp = ops.softargmin_heads(torch.stack(heads, 0))                             # :703-706,725-728,748-753
+        c3 = _classifier(self.classif3, out3)                                          # :747
+        disp = ops.softargmin_heads(torch.stack([c1, c2, c3], 0))                      # :703-706,725-728,748-753
         preds = ops.ecm_aggregate9(disp, w9, scale)                                    # :709-723 (x3)
         return preds[0].unsqueeze(1), preds[1].unsqueeze(1), preds[2].unsqueeze(1)
 
@@ -587,11 +606,11 @@ class _ECMNet(nn.Module):
                 pre1 = pre
             clf = getattr(self, f"classif{i + 1}")
             if i + 1 < self.HOURGLASSES:       # `out` also feeds the next hourglass: the classifier's conv hands it back
-                h, out = _cbn(clf[0], out, relu=True, fork=True)
+                c_i, out = _classifier(clf, out, fork=True)
             else:
-                h = _cbn(clf[0], out, relu=True)
+                c_i = _classifier(clf, out)
             x = out
-            heads.append(clf[2](h).squeeze(1))
+            heads.append(c_i)
         c = torch.stack(heads, 0)                                        # raw classifier outputs [NH,B,Dl,h,w]
         if self.HEAD == "five":                                          # cmfsm_sub_8.py:757-803 (heads NOT accumulated)
             disp = torch.cat([ops.softargmin_heads(c[k:k + 1]) for k in range(c.shape[0])], 0)

@@ -1130,6 +1130,73 @@ class GroupNormAct(torch.autograd.Function):
         return gx, ggamma, gbeta, gskip, None, None
 
 
+class ClassifierTail(torch.autograd.Function):
+    """GroupNorm(32) + ReLU + Conv3d(32 -> 1, k3, pad 1) of a classifier (cmfsm.py:621-634: classifN[0][1], classifN[1],
+    classifN[2]) with the normalised tensor never materialised: x [B,32,D,H,W] is the RAW output of classifN[0][0]; one read
+    pass gives the group statistics (ecm_gn3d_stats) and the 32 -> 1 kernels normalise + rectify while they stage x
+    (ecm_conv3d_c1_gn_fwd / _gn_wgrad).  Saves the GroupNorm kernel's write and the convolution's read of the 849 MB tensor
+    (batch 4) per head, and the tensor itself.  Backward: gh = dgrad(gy) (w.r.t. the normalised tensor), the GroupNorm backward
+    with the ReLU mask recomputed from x."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w):
+        _chk(x, gamma, beta, w)
+        x, gamma, beta, w = _c(x), _c(gamma), _c(beta), _c(w)
+        B, Cc, D, H, W = x.shape
+        if Cc != 32 or tuple(w.shape) != (1, 32, 3, 3, 3):
+            raise RuntimeError(f"classifier_tail: x {tuple(x.shape)}, w {tuple(w.shape)}: the fused tail exists for 32 -> 1 only")
+        S = D * H * W
+        stats = torch.empty(B, GN_GROUPS, 2, device=x.device, dtype=x.dtype)
+        nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
+        scratch = _scratch(nb, x.device)
+        _gn_call("ecm_gn3d_stats", _p(x), _p(stats), _p(scratch), C.c_longlong(nb), B, Cc, C.c_longlong(S), C.c_float(GN_EPS), _stream())
+        y = torch.empty(B, 1, D, H, W, device=x.device, dtype=x.dtype)
+        _lib.call("ecm_conv3d_c1_gn_fwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(w), _p(y), B, Cc, D, H, W, _stream())
+        ctx.save_for_backward(x, stats, gamma, beta, w)
+        ctx.side_ok = True
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, gamma, beta, w = ctx.saved_tensors
+        gy = _c(gy)
+        B, Cc, D, H, W = x.shape
+        S = D * H * W
+
+        def wfn():
+            def now():
+                g = _empty_like(w)
+                nbw = _lib.query("ecm_conv3d_c1_wgrad_scratch_bytes", B, Cc, D, H, W)
+                sc = _scratch(nbw, x.device)
+                _lib.call("ecm_conv3d_c1_gn_wgrad", _p(x), _p(stats), _p(gamma), _p(beta), _p(gy), _p(g), _p(sc), C.c_longlong(nbw),
+                          B, Cc, D, H, W, _stream())
+                return g
+            return _on_side(now, w, x, gy, stats, gamma, beta)
+
+        def dfn():
+            gh = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+            _lib.call("ecm_conv3d_c1_dgrad", _p(gy), _p(w), _p(gh), B, Cc, D, H, W, _stream())
+            return gh
+        gh, gw = _launch_pair(wfn if ctx.needs_input_grad[3] else None, dfn)
+        gx = _empty_like(x)
+        ggamma, gbeta = _empty_like(gamma), _empty_like(gamma)
+        nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
+        scratch = _scratch(nb, x.device)
+        if _gn_capturing():
+            _gn_call("ecm_gn3d_bwd", _p(x), _p(stats), _p(gamma), _p(beta), _p(None), _p(gh), _p(gx), _p(None), _p(ggamma),
+                     _p(gbeta), _p(scratch), C.c_longlong(nb), B, Cc, C.c_longlong(S), 1, _stream())
+        else:
+            cl = _gn_cluster(B, x.device)
+            _gn_call("ecm_gn3d_bwd_p", _p(x), _p(stats), _p(gamma), _p(beta), _p(None), _p(gh), _p(gx), _p(None), _p(ggamma),
+                     _p(gbeta), _p(scratch), C.c_longlong(nb), _p(cl), C.c_longlong(cl.numel()), B, Cc, C.c_longlong(S), 1, _stream())
+        return gx, ggamma, gbeta, gw
+
+
+def classifier_tail(x, gamma, beta, w):
+    """relu(GroupNorm32(x)) -> Conv3d(32 -> 1): see ClassifierTail."""
+    return ClassifierTail.apply(x, gamma, beta, w)
+
+
 FLYING3D_MEAN, FLYING3D_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # cmf/loader/Flying3d.py:26-27
 
 

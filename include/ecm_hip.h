@@ -174,6 +174,15 @@ int ecm_conv3d_c1_dgrad(const float* gy, const float* w, float* gx, int B, int C
 long long ecm_conv3d_c1_wgrad_scratch_bytes(int B, int Ci, int D, int H, int W);
 int ecm_conv3d_c1_wgrad(const float* x, const float* gy, float* gw, void* scratch, long long scratch_bytes,
                         int B, int Ci, int D, int H, int W, void* stream);
+/* ABI 4: the whole tail of a classifier, GroupNorm(32) + ReLU + Conv3d(32 -> 1) (cmfsm.py:621-634: classifN[0][1], [1], [2]),
+ * with the normalisation applied while x is staged: x is the RAW output of classifN[0][0] and mean_rstd [B,32,2] its group
+ * statistics from ecm_gn3d_stats; h = relu(gn(x)) is never written.  Ci must be 32 (one channel per group).  fwd: y [B,1,D,H,W];
+ * wgrad: gw [1,32,27] = sum gy (x) h.  The data gradient w.r.t. h is ecm_conv3d_c1_dgrad, the GroupNorm backward
+ * ecm_gn3d_bwd with y == NULL (ReLU mask recomputed from x). */
+int ecm_conv3d_c1_gn_fwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* w,
+                         float* y, int B, int Ci, int D, int H, int W, void* stream);
+int ecm_conv3d_c1_gn_wgrad(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* gy,
+                           float* gw, void* scratch, long long scratch_bytes, int B, int Ci, int D, int H, int W, void* stream);
 
 /* ConvTranspose3d k=3, stride 2, pad 1, output_padding 1 (cmfsm.py:262-281): x [B,Ci,D,H,W] -> y [B,Co,Do,Ho,Wo],
  * Do = 2D (or 2D-1 when used as the data gradient of a stride-2 conv over an odd extent).

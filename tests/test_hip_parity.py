@@ -879,3 +879,57 @@ def test_dilated_layer_as_phase_planes(ecm, B, C, H, W, d):
     close(y, ref, 1e-4, 2e-5)
     close(xg.grad, xs.grad, 1e-4, 2e-5)
     close(wg.grad, ws.grad, 1e-4, 1e-4 * float(ws.grad.abs().max()))
+
+
+# ------------------------------------------------------------------ fused classifier tail (round 4): GN + ReLU + Conv3d(32 -> 1)
+@pytest.mark.parametrize("B,dims", [(1, (8, 8, 12)), (2, (5, 7, 33)), (1, (3, 17, 40)), (2, (9, 20, 65))])
+def test_classifier_tail_vs_torch_and_unfused(ecm, B, dims):
+    """ops.classifier_tail (GroupNorm(32) + ReLU applied while the 32 -> 1 kernels stage x; cmfsm.py:621-634) against the
+    CPU composition F.conv3d(F.relu(F.group_norm(x))) with autograd, and against the three separate HIP stages: forward and
+    the gradients w.r.t. x, gamma, beta and the 32 -> 1 weight."""
+    ops = ecm.ops
+    x = seeded("ct.x", B, 32, *dims) * 1.5 + 0.3
+    gm, bt = 1.0 + 0.2 * seeded("ct.g", 32), 0.2 * seeded("ct.b", 32)
+    w = seeded("ct.w", 1, 32, 3, 3, 3) * (2.0 / (27 * 32)) ** 0.5
+    G = seeded("ct.G", B, 1, *dims)
+    ref_in = [t.clone().requires_grad_() for t in (x, gm, bt, w)]
+    ref = F.conv3d(F.relu(F.group_norm(ref_in[0], 32, ref_in[1], ref_in[2], 1e-5)), ref_in[3], None, 1, 1)
+    ref.backward(G)
+    a = [dev(t).requires_grad_() for t in (x, gm, bt, w)]
+    y = ops.classifier_tail(*a)
+    y.backward(dev(G))
+    b = [dev(t).requires_grad_() for t in (x, gm, bt, w)]
+    y2 = ops.conv3d_k3(ops.group_norm_act(b[0], b[1], b[2], None, True), b[3], 1)
+    y2.backward(dev(G))
+    close(y, ref, 1e-4, 1e-5)
+    close(y, y2, 1e-5, 1e-6)                                   # same arithmetic; only the statistics' summation order differs
+    for t, u, r, name in zip(a, b, ref_in, ("x", "gamma", "beta", "w")):
+        close_grad(t.grad, r.grad, 2e-4)
+        close_grad(t.grad, u.grad, 2e-5)
+    ecm.ops.check_async_errors()
+
+
+def test_classifier_tail_in_the_model_equals_the_separate_stages(ecm, cmfsm_sd):
+    """models.C1_GN_FUSE on / off: same predictions and parameter gradients of the classifiers on a small hot path."""
+    mdl = importlib.import_module("explicit-context-mapping-for-stereo-matching_amd.models")
+    model = ecm.get_model("cmfsm")
+    model.load_state_dict(cmfsm_sd)
+    model = model.cuda().train()
+    lr_l, hr_l, lr_r = (dev(seeded(n, 1, 32, *s)) for n, s in (("ctm.lr_l", (8, 16)), ("ctm.hr_l", (32, 64)), ("ctm.lr_r", (8, 16))))
+    res = {}
+    prev = mdl.C1_GN_FUSE
+    try:
+        for flag in (True, False):
+            mdl.C1_GN_FUSE = flag
+            model.zero_grad(set_to_none=True)
+            preds = model.hot_path(lr_l, hr_l, lr_r)
+            sum((p * p).mean() for p in preds).backward()
+            res[flag] = ([p.detach().clone() for p in preds],
+                         {k: p.grad.clone() for k, p in model.named_parameters() if k.startswith("classif") and p.grad is not None})
+    finally:
+        mdl.C1_GN_FUSE = prev
+    for pa, pb in zip(res[True][0], res[False][0]):
+        close(pa, pb, 0, 2e-3)                                  # px; the heads' statistics differ in summation order only
+    assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) == 12
+    for k in res[True][1]:
+        close_grad(res[True][1][k], res[False][1][k], 2e-3)

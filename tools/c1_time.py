@@ -35,3 +35,20 @@ for B in (1, 4):
     d = t(lambda: torch.autograd.grad(yy, xg, g, retain_graph=True))
     wgt = t(lambda: torch.autograd.grad(yy, wg, g, retain_graph=True))
     print(f"B={B}: fwd {f:.3f} ms ({gb / f:.0f} GB/s)  dgrad {d:.3f} ms ({gb / d:.0f} GB/s)  wgrad {wgt:.3f} ms ({gb / wgt:.0f} GB/s)  max|err| {err:.2e}", flush=True)
+
+# round 4: the fused tail (GroupNorm + ReLU on load) against GroupNorm kernel + 32 -> 1 convolution
+import torch as _t
+x = _t.randn(4, 32, 48, 144, 240, device="cuda")
+gm, bt = _t.ones(32, device="cuda"), _t.zeros(32, device="cuda")
+w1 = _t.randn(1, 32, 3, 3, 3, device="cuda") * 0.05
+def _tm(fn, n=10):
+    for _ in range(3): fn()
+    _t.cuda.synchronize()
+    s, e = _t.cuda.Event(enable_timing=True), _t.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); _t.cuda.synchronize()
+    return s.elapsed_time(e) / n
+with _t.no_grad():
+    print(f"B=4 classifier tail: GroupNorm kernel + c1 conv {_tm(lambda: ops.conv3d_k3(ops.group_norm_act(x, gm, bt, None, True), w1, 1)):.3f} ms   "
+          f"fused (stats + normalise on load) {_tm(lambda: ops.classifier_tail(x, gm, bt, w1)):.3f} ms")

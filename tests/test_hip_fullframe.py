@@ -50,18 +50,28 @@ def _run(ecm, model, left, right):
     """The model's forward, stage by stage, so that the intermediate tensors of the fixture can be read."""
     B = left.shape[0]
     cap = {}
-    hooks = [getattr(model, f"classif{k}")[2].register_forward_hook(lambda m, i, o, k=k: cap.__setitem__(k, o.detach()))
-             for k in (1, 2, 3)]
+    # the raw classifier outputs: the stack the model hands to the soft-argmin kernel (with the fused classifier tail of
+    # round 4 the 32 -> 1 layers are no longer modules that a forward hook could see)
+    real = ecm.ops.softargmin_heads
+
+    def spy(c):
+        cap["c"] = c.detach()
+        return real(c)
+    ecm.ops.softargmin_heads = spy
+    try:
+        with torch.no_grad():
+            lr, _, hr = model.feature_extraction(torch.cat([left, right], 0), head=B)
+            w9 = model.mapping_matrix.weights(lr[:B], hr)
+            preds = model.hot_path(lr[:B], hr, lr[B:])
+    finally:
+        ecm.ops.softargmin_heads = real
     with torch.no_grad():
-        lr, _, hr = model.feature_extraction(torch.cat([left, right], 0), head=B)
-        w9 = model.mapping_matrix.weights(lr[:B], hr)
-        preds = model.hot_path(lr[:B], hr, lr[B:])
         whole = model(left, right)
-    for h in hooks:
-        h.remove()
     for a, b in zip(preds, whole):
         assert torch.equal(a, b)                                   # the staged run IS the forward
-    return dict(o1=preds[0], o2=preds[1], o3=preds[2], lr_l=lr[:B], lr_r=lr[B:], w9=w9, c1=cap[1], c2=cap[2], c3=cap[3])
+    c = cap["c"]                                                  # [3,B,D',h,w]
+    return dict(o1=preds[0], o2=preds[1], o3=preds[2], lr_l=lr[:B], lr_r=lr[B:], w9=w9, c1=c[0].unsqueeze(1), c2=c[1].unsqueeze(1),
+                c3=c[2].unsqueeze(1))
 
 
 def _sub(k, t):

@@ -356,7 +356,7 @@ def main():
     dt = time.perf_counter() - t0
     # second pass, outside the timed region: the dominant kernel and the kernels furthest below their roofline are
     # event-timed per launch on the launch stream (torch's current stream, the one every kernel of the step is launched on)
-    TIMED = ("ecm_conv_wino_fwd", "ecm_conv3d_k3_fwd", "ecm_conv3d_k3_wgrad", "ecm_conv3d_c1_fwd", "ecm_weights9_fwd",
+    TIMED = ("ecm_conv_wino_fwd", "ecm_conv3d_k3_fwd", "ecm_conv3d_k3_wgrad", "ecm_conv3d_c1_fwd", "ecm_conv3d_c1_gn_fwd", "ecm_weights9_fwd",
              "ecm_weights9_bwd", "ecm_deconv3d_k3s2_fwd")
     # The timed steps run the weight gradients on a second stream, under the data-gradient / GroupNorm chain (ops._on_side):
     # a launch then shares the device and its duration says nothing about the kernel.  For this pass they go back onto the
@@ -575,12 +575,12 @@ def main():
                                      "ms_per_step": tot / n_pass2,
                                      "of_which_32to32_fullres": ({"frac": bf / (bt * 1e-3) / 1e12 * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS,
                                                                   "avg_launch_ms": bt / len(big), "launches_timed": len(big)} if big else None)}
-        c1 = [(s, e, a) for (s, e, a) in timers.get("ecm_conv3d_c1_fwd", [])]                     # (B,Ci,D,H,W)
+        c1 = [(s, e, a) for n_ in ("ecm_conv3d_c1_fwd", "ecm_conv3d_c1_gn_fwd") for (s, e, a) in timers.get(n_, [])]   # (B,Ci,D,H,W)
         if c1:
             tot = sum(s.elapsed_time(e) for s, e, _ in c1)
             byt = sum((a[1] + 1) * 4.0 * a[0] * a[2] * a[3] * a[4] for _, _, a in c1)
             gbs = byt / (tot * 1e-3) / 1e9
-            worst["conv3d_c1_fwd"] = {"kernel": "conv3d_c1_fwd (classifier 32->1)", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+            worst["conv3d_c1_fwd"] = {"kernel": "conv3d_c1_fwd_v (classifier 32->1; since round 4 with GroupNorm + ReLU applied on load)", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
                                       "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "launches_timed": len(c1), "avg_launch_ms": tot / len(c1)}
         ew = [(s, e, a) for (s, e, a) in timers.get("ecm_weights9_fwd", [])]                      # (B,h,w,s)
         if ew:

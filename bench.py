@@ -281,9 +281,12 @@ def main():
     rank, world, _ = ecm_dist.init_from_env(backend, device=local)
     assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     devices = min(world, ndev)          # distinct GPUs in use: ranks share devices round-robin only under gloo
-    if world > ndev:
+    shared_device = world > ndev
+    if shared_device:
         # several PROCESSES on one device: the one-pass GroupNorm kernels wait across workgroups, which is only safe to
-        # rely on when at most a few launches share the device -- take the two-stage kernels (no inter-workgroup waits)
+        # rely on when at most a few launches share the device -- take the two-stage kernels (no inter-workgroup waits);
+        # and keep the weight gradients on the main stream: with two processes on one device every extra stream is one more
+        # hardware queue to time-slice (measured in round 4: 4.3 s per step with the side stream, 49 ms without)
         ops.gn_cluster_mode(0)
     dev = torch.device("cuda", local)
     # The reference sets cudnn.benchmark=True (train.py:26); on ROCm that means an exhaustive MIOpen search per conv
@@ -305,7 +308,7 @@ def main():
     ddp = opt = None
     if args.mode == "train":
         model.train()
-        ddp = ecm_dist.FlatBucketDDP(model, world)
+        ddp = ecm_dist.FlatBucketDDP(model, world, overlap_wgrad=not shared_device)
         opt = torch.optim.Adam(ddp.params, lr=1e-3, betas=(0.9, 0.999), fused=True)   # train.py:85-86 (fused: same update rule)
 
     def train_step(l, r, g):

@@ -43,7 +43,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ecm.ops.gn_cluster_mode(0)                    # ranks share the device: two-stage GroupNorm (no inter-workgroup waits)
     model = _model(ecm)
-    ddp = D.FlatBucketDDP(model, world, late_module="feature_extraction")
+    ddp = D.FlatBucketDDP(model, world, late_module="feature_extraction", overlap_wgrad=False)   # (ranks share the device)
     left, right, gt = (t[rank:rank + 1].cuda() for t in _inputs())
     grads, early = [], []
     for _ in range(2):                            # step 0 learns the hook count, step 1 takes the overlapped path

@@ -134,6 +134,122 @@ __global__ __launch_bounds__(256) void costvol_conv_gq(const float* __restrict__
 }
 
 
+// ---- row-staged forms (round 4) -----------------------------------------------------------------------------------------
+// The element-wise kernels above issue two 4-byte gathers per output (forward, 2.4 TB/s of unique traffic) and read gy twice
+// (backward: once per class family, 3.7 TB/s).  Here one workgroup owns one (b, co, y) row set: forward stages the 15 P rows
+// and 6 Qp rows (21 w + 12 floats) in LDS with 16-byte coalesced loads and writes the D x w outputs as 16-byte streaming
+// stores; backward stages the D x w gradients once and produces both class families from LDS.  Same per-element arithmetic and
+// the same order of additions as the element-wise kernels (bit-identical results); those stay as the path for rows that do not
+// fit (LDS) or are not a multiple of 4 wide.
+__global__ __launch_bounds__(256) void costvol_conv_assemble_rows(const float* __restrict__ P, const float* __restrict__ Qp,
+                                                                  float* __restrict__ y, int Co, int D, int h, int w) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wq = w + 2;
+    float* Ps = smem;                        // [15][w]
+    float* Qs = smem + NCP * w;              // [6][wq]
+    int r = blockIdx.x;
+    const int yy = r % h; r /= h;
+    const int co = r % Co;
+    const int b = r / Co;
+    const size_t hw = (size_t)h * w, hq = (size_t)h * wq;
+    const float* Pb = P + (((size_t)b * NCP) * Co + co) * hw + (size_t)yy * w;
+    const float* Qb = Qp + (((size_t)b * NCQ) * Co + co) * hq + (size_t)yy * wq;
+    const int w4 = w >> 2;
+    for (int i = threadIdx.x; i < NCP * w4; i += 256) {
+        const int c = i / w4, x4 = i - c * w4;
+        reinterpret_cast<float4*>(Ps + c * w)[x4] = reinterpret_cast<const float4*>(Pb + (size_t)c * Co * hw)[x4];
+    }
+    for (int i = threadIdx.x; i < NCQ * wq; i += 256) {          // rows of w + 2: 8-byte aligned at best, plain loads
+        const int c = i / wq, j = i - c * wq;
+        Qs[i] = Qb[(size_t)c * Co * hq + j];
+    }
+    __syncthreads();
+    float* yb = y + (((size_t)b * Co + co) * D) * hw + (size_t)yy * w;
+    for (int i = threadIdx.x; i < D * w4; i += 256) {
+        const int d = i / w4, x0 = (i - d * w4) * 4;
+        const int e = edge_of(d, D);
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + k, delta = d - x;
+            float acc = 0.f;
+            if (delta < 3) {
+                const int dc = (delta < -2 ? -2 : delta) + 2;
+                acc = Ps[(dc * 3 + e) * w + x] + Qs[(e * 2 + (x == w - 1 ? 1 : 0)) * wq + (x - d + 2)];
+            }
+            v[k] = acc;
+        }
+        ecm_st_stream(yb + (size_t)d * hw + x0, make_float4(v[0], v[1], v[2], v[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void costvol_conv_grad_rows(const float* __restrict__ gy, float* __restrict__ gP,
+                                                              float* __restrict__ gQp, int Co, int D, int h, int w) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* G = smem;                         // [D][w]
+    const int wq = w + 2;
+    int r = blockIdx.x;
+    const int yy = r % h; r /= h;
+    const int co = r % Co;
+    const int b = r / Co;
+    const size_t hw = (size_t)h * w, hq = (size_t)h * wq;
+    const float* gb = gy + (((size_t)b * Co + co) * D) * hw + (size_t)yy * w;
+    const int w4 = w >> 2;
+    for (int i = threadIdx.x; i < D * w4; i += 256) {
+        const int d = i / w4, x4 = i - d * w4;
+        reinterpret_cast<float4*>(G + d * w)[x4] = reinterpret_cast<const float4*>(gb + (size_t)d * hw)[x4];
+    }
+    __syncthreads();
+    // reference half: the adjoint of the 15 wedge / depth-edge classes (same order of additions as costvol_conv_gp)
+    for (int x = threadIdx.x; x < w; x += 256) {
+        float out[NCP];
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) out[c] = 0.f;
+        const int da = x - 2 < D - 1 ? x - 2 : D - 1;
+        if (da >= 0) out[0] = G[x];
+        {
+            float s = 0.f;
+            const int hi = da < D - 2 ? da : D - 2;
+            for (int d = 1; d <= hi; ++d) s += G[d * w + x];
+            out[1] = s;
+        }
+        if (da >= D - 1) out[2] = G[(D - 1) * w + x];
+#pragma unroll
+        for (int k = 1; k <= 4; ++k) {
+            const int d = x - 2 + k;
+            if (d >= 0 && d < D) {
+                const float v = G[d * w + x];
+                const int e = edge_of(d, D);
+                out[k * 3 + 0] = e == 0 ? v : 0.f;
+                out[k * 3 + 1] = e == 1 ? v : 0.f;
+                out[k * 3 + 2] = e == 2 ? v : 0.f;
+            }
+        }
+        float* o = gP + (((size_t)b * NCP) * Co + co) * hw + (size_t)yy * w + x;
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) o[(size_t)c * Co * hw] = out[c];
+    }
+    // target half: sums along the diagonals x = u + d (same order as costvol_conv_gq)
+    for (int j = threadIdx.x; j < wq; j += 256) {
+        const int u = j - 2;
+        float first = 0.f, mid = 0.f, last = 0.f, firstr = 0.f, midr = 0.f, lastr = 0.f;
+        const int d0 = u < 0 ? -u : 0;
+        const int d1 = w - 1 - u < D - 1 ? w - 1 - u : D - 1;
+        for (int d = d0; d <= d1; ++d) {
+            const int x = u + d;
+            const float v = G[d * w + x];
+            const bool rb = x == w - 1;
+            if (d == 0) { if (rb) firstr += v; else first += v; }
+            else if (d == D - 1) { if (rb) lastr += v; else last += v; }
+            else { if (rb) midr += v; else mid += v; }
+        }
+        float* o = gQp + (((size_t)b * NCQ) * Co + co) * hq + (size_t)yy * wq + j;
+        o[0 * Co * hq] = first; o[1 * Co * hq] = firstr;
+        o[2 * Co * hq] = mid;   o[3 * Co * hq] = midr;
+        o[4 * Co * hq] = last;  o[5 * Co * hq] = lastr;
+    }
+}
+
 // ---- class-indexed 2-D kernels of the collapsed first convolution (what ops.costvol_conv3d builds every step) ----------------
 // wP[x][co][ci][kh][kw]    = sum_kd mP[x][kd][kw]        w[co][ci][kd][kh][kw]         x = (clamp(d-x,-2,2)+2)*3 + edge, 15 classes
 // wQ[x][co][ci][kh][ku]    = sum_{kd,kw} mQ[x][kd][kw][ku] w[co][C+ci][kd][kh][kw]     x = edge*2 + (column == w-1), 6 classes
@@ -212,6 +328,15 @@ extern "C" int ecm_costvol_conv_assemble_fwd(const float* P, const float* Qp, fl
     if (D < 2) return ECM_EUNSUP;
     const long long n = (long long)B * Co * D * h * w;
     hipStream_t st = ecm_stream(stream);
+    {
+        const long long rows = (long long)B * Co * h;
+        const size_t lds = (size_t)(NCP * w + NCQ * (w + 2)) * sizeof(float);
+        const bool aligned = (reinterpret_cast<size_t>(P) | reinterpret_cast<size_t>(y)) % 16 == 0;
+        if (w % 4 == 0 && aligned && lds <= 64 * 1024 && rows <= 0x7fffffffLL) {
+            hipLaunchKernelGGL(costvol_conv_assemble_rows, dim3((unsigned)rows), dim3(256), lds, st, P, Qp, y, Co, D, h, w);
+            return ECM_LAUNCH_RESULT();
+        }
+    }
     if (w % 4 == 0) {
         const long long nv = n / 4;
         hipLaunchKernelGGL(costvol_conv_assemble<true>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, P, Qp, y, Co, D, h,
@@ -228,6 +353,14 @@ extern "C" int ecm_costvol_conv_assemble_bwd(const float* gy, float* gP, float* 
     ECM_CHECK_ARG(gy && gP && gQp && B > 0 && Co > 0 && h > 0 && w > 0);
     if (D < 2) return ECM_EUNSUP;
     hipStream_t st = ecm_stream(stream);
+    {
+        const long long rows = (long long)B * Co * h;
+        const size_t lds = (size_t)D * w * sizeof(float);
+        if (w % 4 == 0 && reinterpret_cast<size_t>(gy) % 16 == 0 && lds <= 64 * 1024 && rows <= 0x7fffffffLL) {
+            hipLaunchKernelGGL(costvol_conv_grad_rows, dim3((unsigned)rows), dim3(256), lds, st, gy, gP, gQp, Co, D, h, w);
+            return ECM_LAUNCH_RESULT();
+        }
+    }
     const long long tp = (long long)B * Co * h * w, tq = (long long)B * Co * h * (w + 2);
     hipLaunchKernelGGL(costvol_conv_gp, dim3((unsigned)((tp + 255) / 256)), dim3(256), 0, st, gy, gP, Co, D, h, w, tp);
     hipLaunchKernelGGL(costvol_conv_gq, dim3((unsigned)((tq + 255) / 256)), dim3(256), 0, st, gy, gQp, Co, D, h, w, tq);

@@ -933,3 +933,39 @@ def test_classifier_tail_in_the_model_equals_the_separate_stages(ecm, cmfsm_sd):
     assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) == 12
     for k in res[True][1]:
         close_grad(res[True][1][k], res[False][1][k], 2e-3)
+
+
+@pytest.mark.parametrize("B,Co,D,h,w", [(1, 32, 6, 5, 16), (2, 8, 12, 3, 36), (1, 32, 48, 4, 240), (1, 4, 2, 3, 8), (1, 4, 20, 2, 12)])
+def test_costvol_assembly_row_staged_equals_elementwise(ecm, B, Co, D, h, w):
+    """ecm_costvol_conv_assemble_{fwd,bwd}: the row-staged kernels of round 4 (one workgroup per (b, co, y), operands in LDS) and
+    the element-wise ones (taken for unaligned / non-multiple-of-4 / oversized rows) must agree BIT FOR BIT -- same per-element
+    arithmetic, same order of additions.  The element-wise path is forced by handing the library a 4-byte-offset copy."""
+    import ctypes as C
+    lib = ecm._lib
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    P = dev(seeded("asm.P", B, 15 * Co, h, w))
+    Q = dev(seeded("asm.Q", B, 6 * Co, h, w + 2))
+    G = dev(seeded("asm.G", B, Co, D, h, w))
+
+    def off(t):                                             # same values, base pointer 4 bytes past a 16-byte boundary
+        buf = torch.empty(t.numel() + 4, device="cuda")
+        v = buf[1:1 + t.numel()].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4
+        return v
+    y_rows = torch.full((B, Co, D, h, w), float("nan"), device="cuda")
+    y_elem = torch.full((B, Co, D, h, w), float("nan"), device="cuda")
+    lib.call("ecm_costvol_conv_assemble_fwd", p(P), p(Q), p(y_rows), B, Co, D, h, w, st)
+    Po = off(P)
+    lib.call("ecm_costvol_conv_assemble_fwd", p(Po), p(Q), p(y_elem), B, Co, D, h, w, st)
+    assert torch.isfinite(y_rows).all() and torch.equal(y_rows, y_elem)
+    outs = []
+    for g in (G, off(G)):
+        gP = torch.full((B, 15 * Co, h, w), float("nan"), device="cuda")
+        gQ = torch.full((B, 6 * Co, h, w + 2), float("nan"), device="cuda")
+        lib.call("ecm_costvol_conv_assemble_bwd", p(g), p(gP), p(gQ), B, Co, D, h, w, st)
+        outs.append((gP, gQ))
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wino|wino2d|wino2d64|wino2d128|wgrad|wino_wgrad|gn|ecmw_bwd|costvol] [B]"""
+"""Launch a few conv kernels only (for rocprofv3 --pmc passes). usage: conv_only.py [conv|wino|wino2d|wino2d64|wino2d128|c1gn|wgrad|wino_wgrad|gn|ecmw_bwd|costvol] [B]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,6 +43,11 @@ elif which == "ecmw_bwd":
     w9 = ops.ecm_weights9(*a)
     g9 = torch.randn_like(w9)
     for _ in range(5): torch.autograd.grad(w9, a, g9, retain_graph=True)
+elif which == "c1gn":                     # the fused classifier tail: GroupNorm statistics + normalise-on-load 32 -> 1 convolution
+    x = torch.randn(B, 32, 48, 144, 240, device=dev); w = torch.randn(1, 32, 3, 3, 3, device=dev) * 0.05
+    gm, bt = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+    with torch.no_grad():
+        for _ in range(5): y = ops.classifier_tail(x, gm, bt, w)
 elif which == "costvol":
     L, R = torch.randn(B, 32, 144, 240, device=dev), torch.randn(B, 32, 144, 240, device=dev)
     for _ in range(5): c = ops.cost_volume(L, R, 48)

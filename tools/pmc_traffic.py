@@ -76,6 +76,10 @@ def main():
             # 16 consecutive floats), ghr + gA9 written
             ("ecm_weights_bwd_kernel_p_B4", "ecm_weights_bwd_kernel_p", ("ew_fetch", "ew_write"), fac.get("read_b32_buffer", 2.0),
              4 * (3 * 32 + 18) * 576 * 960 * 4),
+            # the classifier forward (round 4: with GroupNorm + ReLU on load): 34-float halo rows of a blocked 3-D tile, 4-byte
+            # lanes -> the row factor (bytes of the 128-B lines those rows touch); algorithmic = x once + y
+            ("conv3d_c1_fwd_v_B4", "conv3d_c1_fwd_v", ("c1_fetch", "c1_write"), fac.get("read_b32_rows", 1.0),
+             4 * (32 + 1) * 48 * 144 * 240 * 4),
             ("costvol_fwd_v4_B4", "costvol_fwd", ("cv_fetch", "cv_write"), fac.get("read_b128_global", 2.0),
              4 * (2 * 32 * 48 * 144 * 240 + 2 * 32 * 144 * 240) * 4)):
         f = mean_kib(counters(f"{root}/{dirs[0]}"), sub, "FETCH_SIZE", 1)

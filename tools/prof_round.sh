@@ -14,7 +14,7 @@ unset ECM_WGRAD_OVERLAP
 P="rocprofv3 --kernel-trace --output-format csv"
 echo calib; $P --pmc FETCH_SIZE -d $O/calib_fetch -- $R/tools/micro/fetch_calib > /dev/null 2>&1
 $P --pmc WRITE_SIZE -d $O/calib_write -- $R/tools/micro/fetch_calib > /dev/null 2>&1
-for w in wino:wino wino_wgrad:ww costvol:cv ecmw_bwd:ew conv:conv; do
+for w in wino:wino wino_wgrad:ww costvol:cv ecmw_bwd:ew conv:conv c1gn:c1; do
   k=${w%%:*}; t=${w##*:}
   echo $k; $P --pmc FETCH_SIZE -d $O/${t}_fetch -- python3 $R/tools/conv_only.py $k 4 > /dev/null 2>&1
   $P --pmc WRITE_SIZE -d $O/${t}_write -- python3 $R/tools/conv_only.py $k 4 > /dev/null 2>&1

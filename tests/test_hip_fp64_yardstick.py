@@ -89,6 +89,34 @@ def test_full_cmfsm_train_step_against_fp64_reference(ecm):
     print("worst norm-error ratios vs the yardstick:", worst)
 
 
+def test_full_frame_train_step_against_fp64_reference(ecm):
+    """BASELINE config 2's training step for ONE sample at the SceneFlow frame size (576x960; fixture g12, round 4): the raw
+    frame of oracle/weights.py:fullframe_frame goes through the HIP frame preparation, the model and the fused loss kernel;
+    predictions, loss and EVERY parameter's gradient are held against the reference's own fp64 run with the reference-fp32's
+    distance from it as the yardstick -- the same assertion as at 256x512, at the size the headline is quoted on."""
+    from oracle.weights import fullframe_frame
+    z = _z("g12_full_cmfsm_576x960_fp64")
+    model = ecm.get_model("cmfsm")
+    model.load_state_dict({k: tensor_for(k, v.shape) for k, v in model.state_dict().items()})
+    model = model.cuda().train()
+    frame = torch.from_numpy(fullframe_frame("sceneflow")[None].copy()).cuda()
+    left, right, gt = ecm.ops.frame_prep(frame, [0], [0], 576, 960, split=540, tail=36)
+    o = model(left, right)
+    loss, metrics = ecm.ops.stereo_loss3(o, gt, 192)                 # train.py:162-174 in one kernel
+    loss.backward()
+    ecm.ops.check_async_errors()
+    for i in (1, 2, 3):
+        d64 = (o[i - 1].detach().double().cpu()[..., ::4, ::4] - torch.from_numpy(z[f"o{i}_64"])).abs()
+        r32 = (torch.from_numpy(z[f"o{i}_32"]).double() - torch.from_numpy(z[f"o{i}_64"])).abs()
+        assert float(d64.max()) <= max(2e-3, K * float(r32.max())) and float(d64.mean()) <= max(1e-4 * i + 1e-4, K * float(r32.mean())), \
+            (i, float(d64.max()), float(d64.mean()), float(r32.max()), float(r32.mean()))
+    l64, l32 = float(z["loss_64"]), float(z["loss_32"])
+    assert abs(float(loss.detach()) - l64) <= K * abs(l32 - l64) + 1e-5 * abs(l64), (float(loss.detach()), l64, l32)
+    n_full, worst = _check_params(model, z, "cmfsm 576x960")
+    assert n_full >= 14, n_full
+    print("worst norm-error ratios vs the yardstick (576x960):", worst)
+
+
 _ARCHS64 = {"cmfsm_sub_16": (16, 4, 4, 8), "bilinear_cmf_sub_16": (16, 4, 4, 4), "cmfsm_sub_8": (8, 4, 8, 8)}   # s, h, w, full tensors
 
 

@@ -149,15 +149,30 @@ __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float
     float* yb = y + (size_t)b * Co * DHWo;
     const int md = md0, mh = mh0 + row, mw = mw0 + l31;
     if (md < D && mh < H && mw < W) {
+        // The two width-parity classes of a (depth, height) parity pair are the neighbouring outputs ow = 2 mw, 2 mw + 1: one
+        // 8-byte store instead of two stride-2 4-byte ones (32 lanes then write 256 contiguous bytes per instruction) whenever
+        // the pair is 8-byte aligned, i.e. for even output widths -- every layer of the registered models.
+        const bool pair_ok = (Wo & 1) == 0 && (HWo & 1) == 0 && (DHWo & 1) == 0 && (reinterpret_cast<size_t>(yb) & 7) == 0;
 #pragma unroll
-        for (int cls = 0; cls < 8; ++cls) {
-            const int od = 2 * md + (cls >> 2), oh = 2 * mh + ((cls >> 1) & 1), ow = 2 * mw + (cls & 1);
+        for (int cls = 0; cls < 8; cls += 2) {
+            const int od = 2 * md + (cls >> 2), oh = 2 * mh + ((cls >> 1) & 1), ow = 2 * mw;
             if (od >= Do || oh >= Ho || ow >= Wo) continue;
             float* yp = yb + (size_t)od * HWo + (size_t)oh * Wo + ow;
+            if (pair_ok) {                                     // (ow + 1 < Wo follows from Wo even)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                if (co < Co) yp[(size_t)co * DHWo] = acc[cls][i];
+                for (int i = 0; i < 16; ++i) {
+                    const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    if (co < Co) *reinterpret_cast<float2*>(yp + (size_t)co * DHWo) = make_float2(acc[cls][i], acc[cls + 1][i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    if (co < Co) {
+                        yp[(size_t)co * DHWo] = acc[cls][i];
+                        if (ow + 1 < Wo) yp[(size_t)co * DHWo + 1] = acc[cls + 1][i];
+                    }
+                }
             }
         }
     }

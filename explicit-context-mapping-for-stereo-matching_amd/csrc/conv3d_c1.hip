@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_dgrad(const float* __restrict__
                     a3 = fmaf(wv, g[j][i0 + 3], a3);
                 }
         float* o = op + (size_t)ci * DHW;
-        if (full) *reinterpret_cast<float4*>(o) = make_float4(a0, a1, a2, a3);
+        if (full) ecm_st_stream(o, make_float4(a0, a1, a2, a3));
         else {
             o[0] = a0;
             if (ow + 1 < W) o[1] = a1;

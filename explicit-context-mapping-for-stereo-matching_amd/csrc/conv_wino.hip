@@ -30,7 +30,8 @@ __device__ unsigned long long wino_prof[4 * 8];   // [wave][phase] cycles of one
 #endif
 
 #ifndef ECM_WINO_ST_AUX
-#define ECM_WINO_ST_AUX 0            // cache policy of the epilogue's stores (2 = nt); see profiles/r04_gn_store_policy.txt
+#define ECM_WINO_ST_AUX 2            // cache policy of the epilogue's stores: nt (1-3 % on the 3-D layers, nothing on the 2-D ones;
+                                     // profiles/r04_gn_store_policy.txt, tools/experiments/README.md)
 #endif
 
 namespace {

@@ -162,7 +162,11 @@ __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                    if (co < Co) *reinterpret_cast<float2*>(yp + (size_t)co * DHWo) = make_float2(acc[cls][i], acc[cls + 1][i]);
+                    if (co < Co) {
+                        typedef float f32x2_st __attribute__((ext_vector_type(2)));
+                        const f32x2_st v = {acc[cls][i], acc[cls + 1][i]};
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x2_st*>(yp + (size_t)co * DHWo));     // streaming result
+                    }
                 }
             } else {
 #pragma unroll

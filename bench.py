@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--explicit-cost-volume", action="store_true",
                    help="run the reference's explicit op sequence (4-D concat volume + 64->32 Conv3d) instead of the collapsed 2-D form")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--trace-steps", action="store_true", help="diagnostic: synchronise and print the wall time of every timed step")
     ap.add_argument("--launch-table", default="", help="write the second pass's per-(entry point, shape) device times to this JSON file")
     return ap.parse_args()
 
@@ -353,8 +354,15 @@ def main():
     # time EXACTLY K steps, un-instrumented
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if args.trace_steps:                                   # diagnostic mode (a sync per step; not the headline protocol)
+        for i in range(args.steps):
+            ts = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            note(f"step {i}: {(time.perf_counter() - ts) * 1e3:.1f} ms  (allocator: {torch.cuda.memory_reserved() / 2**30:.1f} GiB reserved)")
+    else:
+        for _ in range(args.steps):
+            step()
     barrier()
     dt = time.perf_counter() - t0
     # second pass, outside the timed region: the dominant kernel and the kernels furthest below their roofline are

@@ -62,4 +62,3 @@ __device__ __forceinline__ void ecm_st_stream(float* p, const float4& v) {
     __builtin_nontemporal_store(t, reinterpret_cast<f32x4_st*>(p));
 #endif
 }
-

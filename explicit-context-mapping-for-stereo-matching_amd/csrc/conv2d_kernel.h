@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int co = grp * COP + ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                if (co < Co) __builtin_nontemporal_store(acc[r][ct][i], yp + (size_t)co * HWo);     // streaming result (common.h: ecm_st_stream)
+                if (co < Co) yp[(size_t)co * HWo] = acc[r][ct][i];
             }
     }
 }

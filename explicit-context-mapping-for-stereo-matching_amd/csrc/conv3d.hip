@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                if (co < Co) __builtin_nontemporal_store(acc[r][ct][i], yp + (size_t)co * DHWo);    // streaming result (common.h: ecm_st_stream)
+                if (co < Co) yp[(size_t)co * DHWo] = acc[r][ct][i];      // (plain: a non-temporal hint measured +-0 here, round 4)
             }
     }
 #ifdef CV_PROFILE

@@ -162,11 +162,9 @@ __global__ __launch_bounds__(256 * CO_TILES) void deconv3d_k3s2_mfma(const float
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                    if (co < Co) {
-                        typedef float f32x2_st __attribute__((ext_vector_type(2)));
-                        const f32x2_st v = {acc[cls][i], acc[cls + 1][i]};
-                        __builtin_nontemporal_store(v, reinterpret_cast<f32x2_st*>(yp + (size_t)co * DHWo));     // streaming result
-                    }
+                    // (plain stores: with the non-temporal hint the quarter-resolution layer, whose 53 MB output the next kernel
+                    //  finds in the caches, ran 11 % slower and the large one the same -- round 4 A/B)
+                    if (co < Co) *reinterpret_cast<float2*>(yp + (size_t)co * DHWo) = make_float2(acc[cls][i], acc[cls + 1][i]);
                 }
             } else {
 #pragma unroll

@@ -353,6 +353,7 @@ def main():
         note(f"warmup step {i + 1}/{args.warmup} done")
     # time EXACTLY K steps, un-instrumented
     barrier()
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     if args.trace_steps:                                   # diagnostic mode (a sync per step; not the headline protocol)
         for i in range(args.steps):
@@ -365,6 +366,10 @@ def main():
             step()
     barrier()
     dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats()
+    device_allocs_timed = int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0))
+    note(f"timed region: {device_allocs_timed} device allocations by the caching allocator, reserved "
+         f"{ms0.get('reserved_bytes.all.current', 0) / 2**30:.1f} -> {ms1.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB")
     # second pass, outside the timed region: the dominant kernel and the kernels furthest below their roofline are
     # event-timed per launch on the launch stream (torch's current stream, the one every kernel of the step is launched on)
     TIMED = ("ecm_conv_wino_fwd", "ecm_conv3d_k3_fwd", "ecm_conv3d_k3_wgrad", "ecm_conv3d_c1_fwd", "ecm_conv3d_c1_gn_fwd", "ecm_weights9_fwd",
@@ -659,6 +664,9 @@ def main():
             "backend": backend if world > 1 else "none (single process)", "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # the timed region must not go to the driver for memory (ops: host run-ahead bound); both figures are of rank 0
+            "device_allocations_in_timed_region": device_allocs_timed,
+            "allocator_reserved_gib": round(ms1.get("reserved_bytes.all.current", 0) / 2**30, 1),
             "config": {"workload": f"{shape_name} D={D} batch={B}/GPU "
                                    f"{'fwd+bwd+Adam (train.py path)' if args.mode == 'train' else 'eval forward (test.py path)'}",
                        "arch": "cmfsm", "global_batch": B * world, "parallelism": f"dp{world}",

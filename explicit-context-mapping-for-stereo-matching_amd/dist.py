@@ -120,6 +120,8 @@ class FlatBucketDDP:
         accumulation (several backwards before allreduce_gradients()) or a second backward over a retained graph therefore
         never start a collective over a bucket that later backwards still write: only the first backward after zero_grad()
         may fire it, and once it has fired any further backward of the step is refused."""
+        from . import ops
+        ops.pace_side_streams()            # the previous step's backward has finished on the device (ops: host run-ahead)
         for p in self.params:
             p.grad = None
         self._armed = True

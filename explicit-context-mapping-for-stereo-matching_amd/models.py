@@ -517,6 +517,8 @@ class cmfsm(nn.Module):
         # cmfsm.py:657-658 runs the shared encoder twice; both images go through it as ONE batch here (GroupNorm has no
         # cross-sample statistics, so the result is identical) -- half the launches, better-filled small layers.
         B = left.shape[0]
+        if torch.is_grad_enabled():
+            ops.pace_side_streams()        # host run-ahead bound: the previous step's side-stream weight gradients have finished
         lr, _, hr = self.feature_extraction(torch.cat([left, right], 0), head=B)      # hr: the left images' map only
         return self.hot_path(lr[:B], hr, lr[B:])
 
@@ -630,6 +632,8 @@ class _ECMNet(nn.Module):
 
     def forward(self, left, right):
         B = left.shape[0]
+        if torch.is_grad_enabled():
+            ops.pace_side_streams()
         lr, _, hr = self.feature_extraction(torch.cat([left, right], 0))      # one encoder pass for both images
         return self.hot_path(lr[:B], hr[:B], lr[B:], hr[B:], out_hw=left.shape[-2:])
 

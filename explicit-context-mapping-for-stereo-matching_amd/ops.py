@@ -603,14 +603,42 @@ def enable_wgrad_overlap(on=True):
     return prev
 
 
-_SIDE = {}                    # device index -> [side stream, join queued for the running backward pass, weights seen since the join]
+_SIDE = {}     # device index -> [side stream, join queued for the running backward pass, weights seen since the join, event behind the last join]
+
+# Host run-ahead (round 4).  The operands of a side-stream launch are recorded on that stream, so the caching allocator hands
+# their blocks out again only once the side stream's work has FINISHED on the device -- unlike main-stream blocks, which it
+# recycles in stream order however far the host runs ahead.  A training loop that never synchronises (the host enqueues a step
+# in 23 ms, the device runs it in 124) therefore found none of the previous steps' blocks free and went to the driver for new
+# ones every step: 320 hipMalloc calls and 40.7 -> 137.5 GiB reserved over 15 steps, and a step time that depended on how fast
+# the driver could hand out memory (2x slower right after another process had released its own: the driver scrubs what it
+# hands out again).  So the host waits, at the start of a training forward (models: hot path) and in front of a pass's first side launch, for the
+# event recorded behind the PREVIOUS pass's join: at most one step's operands are ever pending, the allocator reaches its steady
+# state in the first step, and the device still has the optimiser step + the queued forward to run while the host catches up
+# (no bubble: measured step time unchanged on a fresh device).  ECM_WGRAD_PACE=0 turns the wait off (A/B only).
+_WGRAD_PACE = _os.environ.get("ECM_WGRAD_PACE", "1") != "0"
+
+
+def pace_side_streams():
+    """Block the HOST until the weight gradients of the previous backward pass have finished on the device (returns at once
+    when there were none, or during stream capture).  Bounds the caching allocator's pending side-stream blocks to one pass."""
+    if not _WGRAD_PACE or not _SIDE:
+        return
+    for dev, st in list(_SIDE.items()):
+        ev = st[3]
+        if ev is not None and not torch.cuda.is_current_stream_capturing():
+            ev.synchronize()
 
 
 def join_side_streams():
     """Make the current stream wait for every weight gradient launched so far (a no-op when there is none)."""
     for dev, st in list(_SIDE.items()):                      # (a second device's autograd thread may add its entry meanwhile)
         if st[0] is not None:
-            torch.cuda.current_stream(dev).wait_stream(st[0])
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_stream(st[0])
+            if st[1]:                                        # side work was launched since the last join: mark its end for the pacer
+                if st[3] is None:
+                    st[3] = torch.cuda.Event()
+                st[3].record(cur)
         st[1] = False
         st[2].clear()
 
@@ -623,7 +651,7 @@ def _on_side(fn, w, *operands):
         return fn()
     st = _SIDE.get(dev.index)
     if st is None:
-        st = _SIDE[dev.index] = [torch.cuda.Stream(device=dev), False, set()]
+        st = _SIDE[dev.index] = [torch.cuda.Stream(device=dev), False, set(), None]
     if w.grad is not None or w.data_ptr() in st[2]:
         # The weight already has a gradient (accumulation over several backward passes), or this pass has already produced one
         # for it (a layer used twice in one graph -- the reference calls its encoder once per image): autograd will ADD the
@@ -636,6 +664,8 @@ def _on_side(fn, w, *operands):
     side, main = st[0], torch.cuda.current_stream(dev)
     if side == main:
         return fn()
+    if not st[1]:
+        pace_side_streams()               # first side launch of this pass: the previous pass's operands must have been released
     side.wait_stream(main)
     with torch.cuda.stream(side):
         out = fn()

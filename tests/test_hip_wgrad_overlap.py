@@ -174,3 +174,49 @@ def test_create_graph_and_odd_layouts_stay_on_the_main_stream(ecm):
         assert ref.shape == x.shape
     finally:
         ops.enable_wgrad_overlap(prev)
+
+
+def test_free_running_steps_do_not_grow_the_allocator(ecm):
+    """A loop that never synchronises: the host enqueues steps several times faster than the device runs them.  The operands of
+    the side-stream weight gradients are recorded on that stream, so without the host run-ahead bound (ops.pace_side_streams)
+    every step found the previous steps' blocks still pending and went to the driver for new memory (round 4: 320 device
+    allocations, 40.7 -> 137.5 GiB over 15 steps of the benchmark).  With it, a step after the first allocates nothing new."""
+    from importlib import import_module
+    D = import_module("explicit-context-mapping-for-stereo-matching_amd.dist")
+    ops = ecm.ops
+    if not ops._WGRAD_PACE:
+        pytest.skip("ECM_WGRAD_PACE=0 in the environment")
+    torch.manual_seed(5)
+    model = ecm.get_model("cmfsm").cuda().train()
+    prev = ops.WGRAD_OVERLAP
+    ddp = D.FlatBucketDDP(model, 1)                            # turns the side stream on
+    if not ops.WGRAD_OVERLAP:
+        pytest.skip("ECM_WGRAD_OVERLAP=0 in the environment")
+    opt = torch.optim.Adam(ddp.params, lr=1e-4, fused=True)
+    B, H, W = 2, 256, 512
+    left, right = torch.randn(B, 3, H, W, device="cuda"), torch.randn(B, 3, H, W, device="cuda")
+    gt = torch.rand(B, H, W, device="cuda") * 191
+
+    def step():
+        ddp.zero_grad()
+        loss, count = D.masked_smooth_l1_x3_with_count(model(left, right), gt, 192)
+        ddp.global_mean_loss(loss, count).backward()
+        ddp.allreduce_gradients()
+        opt.step()
+
+    try:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        assert ops._SIDE and any(st[3] is not None for st in ops._SIDE.values()), "no join event behind the side stream's work"
+        before = torch.cuda.memory_stats()
+        for _ in range(8):                                     # no synchronisation in here
+            step()
+        torch.cuda.synchronize()
+        after = torch.cuda.memory_stats()
+        assert after["num_device_alloc"] == before["num_device_alloc"], \
+            (before["num_device_alloc"], after["num_device_alloc"], after["reserved_bytes.all.current"] / 2**30)
+        assert ops._lib.query("ecm_async_status", 1) == 0
+    finally:
+        ops.enable_wgrad_overlap(prev)
+        ops._SIDE.clear()

@@ -392,11 +392,12 @@ def main():
         rows = {}
         for name, evs in timers.items():
             for s_, e_, a in evs:
-                r = rows.setdefault((name, tuple(a) + tuple(getattr(a, "longs", ()))), [0, 0.0])
+                r = rows.setdefault((name, tuple(a), tuple(getattr(a, "longs", ()))), [0, 0.0])
                 r[0] += 1
                 r[1] += s_.elapsed_time(e_)
-        table = [{"entry": k[0], "family": _family(k[0], k[1]), "int_args": list(k[1]),     # (ints, then the 64-bit size arguments) "launches_per_step": v[0] / n_pass2,
-                  "ms_per_step": v[1] / n_pass2, "avg_launch_ms": v[1] / v[0]} for k, v in rows.items()]
+        table = [{"entry": k[0], "family": _family(k[0], k[1]), "int_args": list(k[1]), "size_args": list(k[2]),
+                  "launches_per_step": v[0] / n_pass2, "ms_per_step": v[1] / n_pass2, "avg_launch_ms": v[1] / v[0]}
+                 for k, v in rows.items()]
         table.sort(key=lambda r: -r["ms_per_step"])
         with open(args.launch_table, "w") as f:
             json.dump({"note": "per (C-ABI entry point, integer arguments) device time of one training step; HIP events, "

@@ -34,6 +34,14 @@ def _chk(*ts):
             raise RuntimeError(f"ecm ops are fp32 (got {t.dtype})")
 
 
+def _need(cond, msg):
+    """Operand-shape contract of an op.  The C ABI sees pointers and sizes only: whatever the sizes do not say about a second
+    operand has to be established here, BEFORE the launch -- a kernel reading past a smaller tensor is a device fault, not an
+    exception.  RuntimeError, as the torch ops these replace raise on mismatched shapes."""
+    if not cond:
+        raise RuntimeError(msg() if callable(msg) else msg)
+
+
 def _c(t):
     """Contiguous and 16-byte aligned (the kernels use float4 accesses)."""
     if not t.is_contiguous():
@@ -60,6 +68,8 @@ class CostVolumeConcat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, left, right, ndisp):
         _chk(left, right)
+        _need(left.dim() == 4 and right.shape == left.shape and ndisp >= 1,
+              lambda: f"cost_volume: left {tuple(left.shape)}, right {tuple(right.shape)}, ndisp {ndisp}: two [B,C,h,w] maps of one shape")
         left, right = _c(left), _c(right)
         B, Cc, h, w = left.shape
         cost = torch.empty(B, 2 * Cc, ndisp, h, w, device=left.device, dtype=left.dtype)
@@ -89,9 +99,11 @@ class CostvolConvAssemble(torch.autograd.Function):
     def forward(ctx, P, Qp, ndisp):
         _chk(P, Qp)
         P, Qp = _c(P), _c(Qp)
+        _need(P.dim() == 4 and Qp.dim() == 4, "costvol_conv assemble: P and Qp are [B,classes*Co,h,w(+2)]")
         B, c15, h, w = P.shape
         Co = c15 // 15
-        assert c15 == 15 * Co and Qp.shape == (B, 6 * Co, h, w + 2), (P.shape, Qp.shape)
+        _need(Co >= 1 and c15 == 15 * Co and tuple(Qp.shape) == (B, 6 * Co, h, w + 2) and ndisp >= 2,
+              lambda: f"costvol_conv assemble: P {tuple(P.shape)} / Qp {tuple(Qp.shape)} / D {ndisp}: want [B,15Co,h,w], [B,6Co,h,w+2], D >= 2")
         y = torch.empty(B, Co, ndisp, h, w, device=P.device, dtype=P.dtype)
         _lib.call("ecm_costvol_conv_assemble_fwd", _p(P), _p(Qp), _p(y), B, Co, ndisp, h, w, _stream())
         ctx.dims = (B, Co, ndisp, h, w)
@@ -116,6 +128,8 @@ class ClassWeights(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w):
         _chk(w)
+        _need(w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[1] % 2 == 0,
+              lambda: f"class weights: w {tuple(w.shape)}: want the first 3x3x3 convolution's [Co,2C,3,3,3]")
         w = _c(w)
         Co, C2 = w.shape[:2]
         Cc = C2 // 2
@@ -138,6 +152,8 @@ def costvol_conv3d(left, right, weight, ndisp):
     halves of the concat volume are constant along a line in (d, x), so the 3x3x3 convolution collapses to class-indexed
     2-D convolutions of the two feature maps (3x3 on `left`, sheared 3x5 on `right`) -- see csrc/costvol_conv.hip.
     weight: [Co, 2C, 3, 3, 3] (the reference's dres0[0][0].weight)."""
+    _need(left.dim() == 4 and right.shape == left.shape and weight.dim() == 5,
+          lambda: f"costvol_conv3d: left {tuple(left.shape)}, right {tuple(right.shape)}, weight {tuple(weight.shape)}")
     Cc = left.shape[1]
     if weight.shape[1] != 2 * Cc or ndisp < 2:
         return conv3d_k3(cost_volume(left, right, ndisp), weight, 1)
@@ -158,6 +174,7 @@ class SoftArgminHeads(torch.autograd.Function):
     @staticmethod
     def forward(ctx, c):
         _chk(c)
+        _need(c.dim() == 5 and c.numel() > 0, lambda: f"softargmin_heads: c {tuple(c.shape)}: want [heads,B,D,h,w]")
         c = _c(c)
         NH, B, D, h, w = c.shape
         disp = torch.empty(NH, B, h, w, device=c.device, dtype=c.dtype)
@@ -183,6 +200,7 @@ def softargmin_heads(c):
 def disparity_regression(x):
     """disparityregression.forward (cmfsm.py:120-123): [B,D,h,w] probabilities -> [B,h,w]. Forward only."""
     _chk(x)
+    _need(x.dim() == 4 and x.numel() > 0, lambda: f"disparity_regression: x {tuple(x.shape)}: want [B,D,h,w]")
     x = _c(x)
     B, D, h, w = x.shape
     out = torch.empty(B, h, w, device=x.device, dtype=x.dtype)
@@ -198,8 +216,10 @@ class ECMAggregate9(torch.autograd.Function):
     def forward(ctx, d, w9, scale):
         _chk(d, w9)
         d, w9 = _c(d), _c(w9)
+        _need(d.dim() == 4 and scale >= 1, lambda: f"ecm_aggregate9: d {tuple(d.shape)}, scale {scale}: want [heads,B,h,w]")
         NH, B, h, w = d.shape
-        assert w9.shape == (B, 9, h * scale, w * scale), (w9.shape, d.shape, scale)
+        _need(tuple(w9.shape) == (B, 9, h * scale, w * scale),
+              lambda: f"ecm_aggregate9: w9 {tuple(w9.shape)} for d {tuple(d.shape)} at scale {scale}: want [B,9,h*scale,w*scale]")
         out = torch.empty(NH, B, h * scale, w * scale, device=d.device, dtype=d.dtype)
         _lib.call("ecm_aggregate9_fwd", _p(d), _p(w9), _p(out), NH, B, h, w, scale, _stream())
         ctx.save_for_backward(d, w9)
@@ -221,12 +241,18 @@ def ecm_aggregate9(d, w9, scale):
 
 
 # ------------------------------------------------------------------------------------ a3 ECM weights
+_ECM_MLP_SIZES = (2112, 512, 128, 8)      # similarity_measure1's four 1x1 kernels: 66->32, 32->16, 16->8, 8->1
 class ECMWeights9(torch.autograd.Function):
     """eight_related_context_mapping (cmfsm.py:443-593): lr [B,32,h,w], hr [B,32,H,W] -> w9 [B,9,H,W]."""
 
     @staticmethod
     def forward(ctx, lr, hr, W0, W1, W2, W3):
         _chk(lr, hr, W0, W1, W2, W3)
+        _need(lr.dim() == 4 and hr.dim() == 4 and hr.shape[0] == lr.shape[0] and lr.shape[-1] > 0 and lr.shape[-2] > 0,
+              lambda: f"context weights: lr {tuple(lr.shape)}, hr {tuple(hr.shape)}: want [B,32,h,w] and [B,32,H,W]")
+        _need((W0.numel(), W1.numel(), W2.numel(), W3.numel()) == _ECM_MLP_SIZES,
+              lambda: f"context weights: the similarity MLP's kernels hold {_ECM_MLP_SIZES} values (cmfsm.py:400-427), got "
+                      f"{(W0.numel(), W1.numel(), W2.numel(), W3.numel())}")
         lr, hr = _c(lr), _c(hr)
         W0, W1, W2, W3 = (_c(t) for t in (W0, W1, W2, W3))
         B, Cc, h, w = lr.shape
@@ -278,6 +304,11 @@ class ContextWeights(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lr, hr, W0, W1, W2, W3, variant):
         _chk(lr, hr, W0, W1, W2, W3)
+        _need(lr.dim() == 4 and hr.dim() == 4 and hr.shape[0] == lr.shape[0] and lr.shape[-1] > 0 and lr.shape[-2] > 0,
+              lambda: f"context weights: lr {tuple(lr.shape)}, hr {tuple(hr.shape)}: want [B,32,h,w] and [B,32,H,W]")
+        _need((W0.numel(), W1.numel(), W2.numel(), W3.numel()) == _ECM_MLP_SIZES,
+              lambda: f"context weights: the similarity MLP's kernels hold {_ECM_MLP_SIZES} values (cmfsm.py:400-427), got "
+                      f"{(W0.numel(), W1.numel(), W2.numel(), W3.numel())}")
         lr, hr = _c(lr), _c(hr)
         W0, W1, W2, W3 = (_c(t) for t in (W0, W1, W2, W3))
         B, Cc, h, w = lr.shape
@@ -287,6 +318,7 @@ class ContextWeights(torch.autograd.Function):
             raise ValueError("odd scale between hr and lr features (the reference calls exit() here)")
         if Cc != 32 or hr.shape[1] != 32 or H != h * s or W != w * s:
             raise RuntimeError(f"context_weights: unsupported shapes lr {tuple(lr.shape)} hr {tuple(hr.shape)}")
+        _need(variant in _VARIANT_PLANES, lambda: f"context weights: variant {variant} (0 eight-related, 1 / 2 six-related)")
         out = torch.empty(B, _VARIANT_PLANES[variant], H, W, device=lr.device, dtype=lr.dtype)
         nb = _lib.query("ecm_weights9_scratch_bytes", B, h, w)
         scratch = _scratch(nb, lr.device)
@@ -326,8 +358,12 @@ class VolumeMapping(torch.autograd.Function):
     @staticmethod
     def forward(ctx, c, m5, mt3, scale):
         _chk(c, m5, mt3)
+        _need(c.dim() == 5 and scale >= 1 and c.numel() > 0, lambda: f"volume_mapping: c {tuple(c.shape)}, scale {scale}")
         c, m5, mt3 = _c(c), _c(m5), _c(mt3)
         NH, B, Dl, h, w = c.shape
+        _need(tuple(m5.shape) == (B, 5, h * scale, w * scale) and tuple(mt3.shape) == (B, 3, h * scale, w * scale),
+              lambda: f"volume_mapping: m5 {tuple(m5.shape)} / mt3 {tuple(mt3.shape)} for c {tuple(c.shape)} at scale {scale}: "
+                      "want [B,5,h*scale,w*scale] and [B,3,h*scale,w*scale]")
         out = torch.empty(NH, B, h * scale, w * scale, device=c.device, dtype=c.dtype)
         _lib.call("ecm_volume_mapping_fwd", _p(c), C.c_longlong(B * Dl * h * w), _p(m5), _p(mt3), _p(out), NH, B, Dl, h, w,
                   scale, _stream())
@@ -358,6 +394,8 @@ class TrilinearSoftArgmin(torch.autograd.Function):
     @staticmethod
     def forward(ctx, c, Do, H, W):
         _chk(c)
+        _need(c.dim() == 5 and c.numel() > 0 and Do >= 1 and H >= 1 and W >= 1,
+              lambda: f"trilinear_softargmin: c {tuple(c.shape)} -> ({Do}, {H}, {W})")
         c = _c(c)
         NH, B, Dl, h, w = c.shape
         out = torch.empty(NH, B, H, W, device=c.device, dtype=c.dtype)
@@ -737,6 +775,9 @@ class Conv3dK3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, fork=False, grad_mode=True):
         _chk(x, w)
+        _need(x.dim() == 5 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[1] == x.shape[1] and stride in (1, 2)
+              and x.numel() > 0 and w.shape[0] > 0,
+              lambda: f"conv3d_k3: x {tuple(x.shape)}, w {tuple(w.shape)}, stride {stride}: want [B,Ci,D,H,W], [Co,Ci,3,3,3], stride 1|2")
         ctx.side_ok = w.is_contiguous()        # else the saved weight is a COPY and AccumulateGrad will re-lay the gradient out (see _on_side)
         x, w = _c(x), _c(w)
         ctx.set_materialize_grads(False)
@@ -898,6 +939,10 @@ class Conv2dG(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, dil, pad_top, pad_left, Ho, Wo, fork=False, grad_mode=True):
         _chk(x, w)
+        _need(x.dim() == 4 and w.dim() == 4 and w.shape[1] == x.shape[1] and x.numel() > 0 and w.shape[0] > 0
+              and stride >= 1 and dil >= 1 and pad_top >= 0 and pad_left >= 0 and Ho >= 1 and Wo >= 1,
+              lambda: f"conv2d: x {tuple(x.shape)}, w {tuple(w.shape)}, stride {stride}, dilation {dil}, pad ({pad_top}, {pad_left}), "
+                      f"out ({Ho}, {Wo}): want [B,Ci,H,W] and [Co,Ci,kh,kw]")
         x = _c(x)
         ctx.set_materialize_grads(False)
         Co, Ci, kh, kw = w.shape
@@ -1007,6 +1052,9 @@ class Conv2dPlanes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, fork=False, grad_mode=True):
         _chk(x, w)
+        _need(x.dim() == 5 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.shape[1] == x.shape[1] and x.numel() > 0
+              and w.shape[0] > 0 and _wino_ok(x),
+              lambda: f"conv2d_planes: x {tuple(x.shape)}, w {tuple(w.shape)}: want [B,Ci,P,h,w] and [Co,Ci,3,3] (Winograd path)")
         ctx.side_ok = w.is_contiguous()
         x, w = _c(x), _c(w)
         ctx.set_materialize_grads(False)
@@ -1039,6 +1087,9 @@ class Deconv3dK3S2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         _chk(x, w)
+        _need(x.dim() == 5 and w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and w.shape[0] == x.shape[1] and x.numel() > 0
+              and w.shape[1] > 0,
+              lambda: f"deconv3d_k3s2: x {tuple(x.shape)}, w {tuple(w.shape)}: want [B,Ci,D,H,W] and ConvTranspose3d's [Ci,Co,3,3,3]")
         ctx.side_ok = w.is_contiguous()
         x, w = _c(x), _c(w)
         B, Ci, D, H, W = x.shape
@@ -1108,6 +1159,10 @@ class GroupNormAct(torch.autograd.Function):
         that consumer's gradient into the first `head` samples of gx -- a tensor this node has just produced and nobody else
         has seen, so the in-place add cannot touch memory another holder relies on."""
         _chk(x, gamma, beta, skip)
+        _need(x.dim() >= 3 and x.numel() > 0 and x.shape[1] % GN_GROUPS == 0 and gamma.numel() == x.shape[1] == beta.numel()
+              and (skip is None or skip.shape == x.shape) and 0 <= head <= x.shape[0],
+              lambda: f"group_norm_act: x {tuple(x.shape)}, gamma {tuple(gamma.shape)}, beta {tuple(beta.shape)}, skip "
+                      f"{None if skip is None else tuple(skip.shape)}, head {head}: {GN_GROUPS} groups over C channels, skip of x's shape")
         x, gamma, beta = _c(x), _c(gamma), _c(beta)
         skip = _c(skip) if skip is not None else None
         B, Cc = x.shape[:2]
@@ -1171,6 +1226,8 @@ class ClassifierTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, w):
         _chk(x, gamma, beta, w)
+        _need(x.dim() == 5 and x.numel() > 0 and gamma.numel() == 32 == beta.numel(),
+              lambda: f"classifier_tail: x {tuple(x.shape)}, gamma {tuple(gamma.shape)}, beta {tuple(beta.shape)}")
         x, gamma, beta, w = _c(x), _c(gamma), _c(beta), _c(w)
         B, Cc, D, H, W = x.shape
         if Cc != 32 or tuple(w.shape) != (1, 32, 3, 3, 3):
@@ -1365,6 +1422,7 @@ def stereo_loss3(preds, gt, maxdisp=192, weights=(0.5, 0.7, 1.0)):
 
 def group_norm_act(x, gamma, beta, skip=None, relu=False, head=0):
     """head > 0: returns (y, x[:head]) -- see GroupNormAct.forward."""
+    _need(0 <= int(head) <= x.shape[0], lambda: f"group_norm_act: head {head} of a batch of {x.shape[0]}")
     if head and not (torch.is_grad_enabled() and x.requires_grad):
         return GroupNormAct.apply(x, gamma, beta, skip, bool(relu), 0), x[:head]
     return GroupNormAct.apply(x, gamma, beta, skip, bool(relu), int(head))

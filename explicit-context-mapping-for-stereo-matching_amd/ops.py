@@ -1195,9 +1195,9 @@ class GroupNormAct(torch.autograd.Function):
         B, Cc = x.shape[:2]
         S = x.numel() // (B * Cc)
         gx = _empty_like(x)
-        gskip = _empty_like(x) if ctx.has_skip else None
-        if ctx.has_skip and not ctx.relu:
-            gskip = gy                      # no mask: the skip gradient is gy itself
+        gskip = None
+        if ctx.has_skip:                    # no mask: the skip gradient is gy itself (the same tensor: nobody writes a gradient in place)
+            gskip = _empty_like(x) if ctx.relu else gy
         ggamma, gbeta = _empty_like(gamma), _empty_like(gamma)
         nb = _lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
         scratch = _scratch(nb, x.device)

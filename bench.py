@@ -185,7 +185,16 @@ def launch_ranks(args):
         for line in stream:
             (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
             sys.stdout.flush()
+    import signal
     import threading
+
+    def end_ranks(signum, _frame):                               # the parent is told to stop: the ranks must not outlive it
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        sys.exit(128 + signum)
+    signal.signal(signal.SIGTERM, end_ranks)
+    signal.signal(signal.SIGINT, end_ranks)
     pump = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
     pump.start()
     worst, failed_at = 0, None

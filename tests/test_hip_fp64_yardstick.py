@@ -33,9 +33,25 @@ def _z(name):
         return {k: z[k] for k in z.files}
 
 
-def _check_params(model, z, label, skip_prefix=None):
-    worst = []
+def _check_params(model, z, label, skip_prefix=None, population=False):
+    """Every parameter's gradient against the reference's fp64 run.  Per parameter: norm and a random projection (a norm cannot
+    see a permuted gradient; the projection can) within K x the reference-fp32's own distance from fp64 (+ FLOOR), and the
+    stored full tensors element-wise likewise.
+
+    `population` (the full-frame fixtures g12 / g12k): at random initialisation the gradients of the first encoder layers carry
+    ~1e-3 of relative noise from ReLU / LeakyReLU decisions that flip with ANY change of rounding, the reference's own fp32 run
+    included -- and for a single parameter that run's distance from fp64 is one draw of that noise (1.5e-4 relative for
+    `firstconv.0.1.bias` at 384x1248, where the same run is 2.5e-3 off on `firstconv.2.1.bias` two layers on).  K x one lucky
+    draw is not a bound.  So there a parameter's norm may also be as far off as the reference-fp32's WORST parameter (x 1.25),
+    and what is held tight is the population: median and rms of the relative norm errors over all parameters within 1.5 x the
+    reference-fp32's (measured: median 1.0e-4 vs 1.1e-4, rms 4.4e-4 vs 4.4e-4 at 384x1248; 1.4e-4 vs 1.0e-4, 3.8e-4 vs 4.5e-4
+    at 576x960)."""
+    worst, bad = [], []
     n_full = 0
+    rel_hip, rel_ref = [], []
+    names = [k for k, _ in model.named_parameters() if not (skip_prefix and k.startswith(skip_prefix))]
+    ref_worst = max(abs(float(z["gn32_" + k.replace(".", "_")]) - float(z["gn64_" + k.replace(".", "_")]))
+                    / max(float(z["gn64_" + k.replace(".", "_")]), 1e-30) for k in names) if population else 0.0
     for k, p in model.named_parameters():
         if skip_prefix and k.startswith(skip_prefix):
             continue
@@ -45,11 +61,14 @@ def _check_params(model, z, label, skip_prefix=None):
         g = p.grad.detach().double().cpu() if p.grad is not None else torch.zeros(p.shape, dtype=torch.float64)
         n_hip = float(g.norm())
         p_hip = float((g * seeded("proj:" + k, *g.shape).double()).sum())
-        # every parameter: norm and a random projection (a norm cannot see a permuted gradient; the projection can)
-        tol_n = K * abs(n32 - n64) + FLOOR * n64 + 1e-12
+        tol_n = max(K * abs(n32 - n64) + FLOOR * n64, 1.25 * ref_worst * n64) + 1e-12
         tol_p = K * abs(p32 - p64) + 2e-2 * n64 + 1e-12          # a projection error is ~ |e| x N(0,1): floor at 2 % of |g|
-        assert abs(n_hip - n64) <= tol_n, f"{label} {k}: |g| {n_hip:.6e} vs fp64 {n64:.6e} (reference fp32 {n32:.6e}); tol {tol_n:.2e}"
-        assert abs(p_hip - p64) <= tol_p, f"{label} {k}: projection {p_hip:.6e} vs fp64 {p64:.6e} (reference fp32 {p32:.6e})"
+        if abs(n_hip - n64) > tol_n:
+            bad.append(f"{label} {k}: |g| {n_hip:.6e} vs fp64 {n64:.6e} (reference fp32 {n32:.6e}); tol {tol_n:.2e}")
+        if abs(p_hip - p64) > tol_p:
+            bad.append(f"{label} {k}: projection {p_hip:.6e} vs fp64 {p64:.6e} (reference fp32 {p32:.6e})")
+        rel_hip.append(abs(n_hip - n64) / max(n64, 1e-30))
+        rel_ref.append(abs(n32 - n64) / max(n64, 1e-30))
         worst.append((abs(n_hip - n64) / max(abs(n32 - n64), FLOOR * n64 / K + 1e-30), k))
         if "g64_" + kk in z:                                     # full tensors
             t64 = torch.from_numpy(z["g64_" + kk])
@@ -57,11 +76,19 @@ def _check_params(model, z, label, skip_prefix=None):
             scale = float(t64.abs().max())
             rms64 = float(t64.pow(2).mean().sqrt())
             emax32, erms32 = float(z["e32max_" + kk]), float(z["e32rms_" + kk])
-            assert float(e.max()) <= K * emax32 + FLOOR * scale, \
-                f"{label} {k}: max |hip - fp64| {float(e.max()):.3e} vs the reference fp32's {emax32:.3e} (scale {scale:.3e})"
-            assert float(e.pow(2).mean().sqrt()) <= K * erms32 + FLOOR * rms64, \
-                f"{label} {k}: rms |hip - fp64| {float(e.pow(2).mean().sqrt()):.3e} vs the reference fp32's {erms32:.3e}"
+            if float(e.max()) > K * emax32 + FLOOR * scale:
+                bad.append(f"{label} {k}: max |hip - fp64| {float(e.max()):.3e} vs the reference fp32's {emax32:.3e} (scale {scale:.3e})")
+            if float(e.pow(2).mean().sqrt()) > K * erms32 + FLOOR * rms64:
+                bad.append(f"{label} {k}: rms |hip - fp64| {float(e.pow(2).mean().sqrt()):.3e} vs the reference fp32's {erms32:.3e}")
             n_full += 1
+    if population:
+        rh, rr = np.array(rel_hip), np.array(rel_ref)
+        stats = (float(np.median(rh)), float(np.median(rr)), float(np.sqrt((rh ** 2).mean())), float(np.sqrt((rr ** 2).mean())))
+        print(f"{label}: relative |g| error over {len(rh)} parameters: median hip {stats[0]:.2e} / reference fp32 {stats[1]:.2e}, "
+              f"rms {stats[2]:.2e} / {stats[3]:.2e}, max {rh.max():.2e} / {rr.max():.2e}")
+        if stats[0] > 1.5 * stats[1] + 1e-5 or stats[2] > 1.5 * stats[3] + 1e-5:
+            bad.append(f"{label}: population of relative norm errors: median {stats[0]:.2e} vs {stats[1]:.2e}, rms {stats[2]:.2e} vs {stats[3]:.2e}")
+    assert not bad, "\n".join(bad)
     return n_full, sorted(worst)[-3:]
 
 
@@ -112,9 +139,36 @@ def test_full_frame_train_step_against_fp64_reference(ecm):
             (i, float(d64.max()), float(d64.mean()), float(r32.max()), float(r32.mean()))
     l64, l32 = float(z["loss_64"]), float(z["loss_32"])
     assert abs(float(loss.detach()) - l64) <= K * abs(l32 - l64) + 1e-5 * abs(l64), (float(loss.detach()), l64, l32)
-    n_full, worst = _check_params(model, z, "cmfsm 576x960")
+    n_full, worst = _check_params(model, z, "cmfsm 576x960", population=True)
     assert n_full >= 14, n_full
     print("worst norm-error ratios vs the yardstick (576x960):", worst)
+
+
+def test_kitti_frame_train_step_against_fp64_reference(ecm):
+    """BASELINE config 4's per-GPU workload (fixture g12k, round 4): the KITTI-shaped raw frame (375x1242) through the HIP
+    top / left repeat padding to 384x1248 (KITTI.py:98-108), the model and the fused loss (train_kitti.py:186-207); predictions,
+    loss and every parameter's gradient against the reference's fp64 run, the reference-fp32's distance as the yardstick."""
+    from oracle.weights import fullframe_frame
+    z = _z("g12k_full_cmfsm_384x1248_fp64")
+    model = ecm.get_model("cmfsm")
+    model.load_state_dict({k: tensor_for(k, v.shape) for k, v in model.state_dict().items()})
+    model = model.cuda().train()
+    frame = torch.from_numpy(fullframe_frame("kitti")[None].copy()).cuda()
+    left, right, gt = ecm.ops.frame_prep_kitti_eval(frame, 384, 1248)
+    o = model(left, right)
+    loss, metrics = ecm.ops.stereo_loss3(o, gt, 192)
+    loss.backward()
+    ecm.ops.check_async_errors()
+    for i in (1, 2, 3):
+        d64 = (o[i - 1].detach().double().cpu()[..., ::4, ::4] - torch.from_numpy(z[f"o{i}_64"])).abs()
+        r32 = (torch.from_numpy(z[f"o{i}_32"]).double() - torch.from_numpy(z[f"o{i}_64"])).abs()
+        assert float(d64.max()) <= max(2e-3, K * float(r32.max())) and float(d64.mean()) <= max(1e-4 * i + 1e-4, K * float(r32.mean())), \
+            (i, float(d64.max()), float(d64.mean()), float(r32.max()), float(r32.mean()))
+    l64, l32 = float(z["loss_64"]), float(z["loss_32"])
+    assert abs(float(loss.detach()) - l64) <= K * abs(l32 - l64) + 1e-5 * abs(l64), (float(loss.detach()), l64, l32)
+    n_full, worst = _check_params(model, z, "cmfsm 384x1248", population=True)
+    assert n_full >= 14, n_full
+    print("worst norm-error ratios vs the yardstick (384x1248):", worst)
 
 
 _ARCHS64 = {"cmfsm_sub_16": (16, 4, 4, 8), "bilinear_cmf_sub_16": (16, 4, 4, 4), "cmfsm_sub_8": (8, 4, 8, 8)}   # s, h, w, full tensors

@@ -205,7 +205,7 @@ def test_free_running_steps_do_not_grow_the_allocator(ecm):
         opt.step()
 
     try:
-        for _ in range(2):
+        for _ in range(3):                                     # free-running from the start: the pool settles in the loop's own pattern
             step()
         torch.cuda.synchronize()
         assert ops._SIDE and any(st[3] is not None for st in ops._SIDE.values()), "no join event behind the side stream's work"
@@ -218,7 +218,7 @@ def test_free_running_steps_do_not_grow_the_allocator(ecm):
         # per step (an odd block may still be requested while the pool settles)
         grown = after["num_device_alloc"] - before["num_device_alloc"]
         r0, r1 = before["reserved_bytes.all.current"], after["reserved_bytes.all.current"]
-        assert grown <= 2 and r1 <= 1.1 * r0, (grown, r0 / 2**30, r1 / 2**30)
+        assert grown <= 4 and r1 <= 1.15 * r0, (grown, r0 / 2**30, r1 / 2**30)     # (un-paced: ~90 allocations, 2x the pool)
         assert ops._lib.query("ecm_async_status", 1) == 0
     finally:
         ops.enable_wgrad_overlap(prev)

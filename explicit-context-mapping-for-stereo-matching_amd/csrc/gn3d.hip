@@ -295,8 +295,15 @@ constexpr int FUSED_MAX_CPG = 8;
 #define ECM_GN_BWD_MAXV4 20
 #define ECM_GN_BWD_OCC 2
 #endif
+#ifndef ECM_GN_FWDS_MAXV4
+#define ECM_GN_FWDS_MAXV4 24      // forward WITH a residual operand: x and skip both held in registers across the reduction (as the
+                                  // backward holds x and gy), so the pass after the rendezvous only writes.  Round 4: the skip used to be
+                                  // read there, between the stores -- 0.553 -> 0.519 ms at 4 x 32 x 48x144x240, 0.128 -> 0.083 at
+                                  // 8 x 128 x 144x240, 0.157 -> 0.128 at 4 x 64 x 24x72x120 (16: 0.570 / 0.086 / 0.131; 20: 0.532 / 0.080 / 0.129)
+#endif
 constexpr int FWD_MAXV4 = ECM_GN_FWD_MAXV4;   // float4 per thread kept in registers; OCC workgroups per CU overlap one
 constexpr int BWD_MAXV4 = ECM_GN_BWD_MAXV4;   // cluster's wait with another's loads/stores
+constexpr int FWDS_MAXV4 = ECM_GN_FWDS_MAXV4;
 
 // Slice access through buffer descriptors (base = first float4 of this workgroup's slice, num_records = slice bytes):
 // one 32-bit per-thread offset + immediates instead of a 64-bit address per register tile row, and float4s past the
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
                                                            float* __restrict__ y, float* __restrict__ mean_rstd,
                                                            FusedCtl ctl, int C, long long S, int cpg,
                                                            int wpc, int nspans, long long v4_per_wg, float eps) {
-    constexpr int MAXV4 = FWD_MAXV4;
+    constexpr int MAXV4 = SKIP ? FWDS_MAXV4 : FWD_MAXV4;
     __shared__ float sm[2 * THREADS / 64];
     __shared__ double smd[2 * THREADS / 64];
     __shared__ unsigned tick_s, last_s;
@@ -484,8 +491,13 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         // pivot of the span (see gn_pivot): the same for every member of the cluster
         const float K = gn_pivot(x + ((size_t)b * C + (size_t)g * cpg) * S, (long long)cpg * S);
         const unsigned nslice = (unsigned)(v1 - v0), vidx = (unsigned)(wave * MAXV4 * 64 + lane);
-        float4 v[MAXV4];
+        float4 v[MAXV4], kv[SKIP ? MAXV4 : 1];
         float s = 0.f, q = 0.f;
+        const auto kr = slice_rsrc(SKIP ? skip + base + (size_t)v0 * 4 : x, SKIP ? v1 - v0 : 0);
+        if (SKIP) {                                     // the residual operand travels with x: in flight under the reduction
+#pragma unroll
+            for (int j = 0; j < MAXV4; ++j) kv[j] = slice_ld(kr, toff + j * 1024);
+        }
 #pragma unroll
         for (int j = 0; j < MAXV4; ++j) {
             v[j] = slice_ld(xr, toff + j * 1024);
@@ -530,13 +542,12 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         float a, sh;
         gn_affine(mean, rstd, gamma[c], beta[c], a, sh);
         const auto yr = slice_rsrc(y + base + (size_t)v0 * 4, v1 - v0);
-        const auto kr = slice_rsrc(SKIP ? skip + base + (size_t)v0 * 4 : x, SKIP ? v1 - v0 : 0);
 #pragma unroll
         for (int j = 0; j < MAXV4; ++j) {
             float4 o = v[j];
             o.x = __builtin_fmaf(o.x, a, sh); o.y = __builtin_fmaf(o.y, a, sh);
             o.z = __builtin_fmaf(o.z, a, sh); o.w = __builtin_fmaf(o.w, a, sh);
-            if (SKIP) { const float4 k = slice_ld(kr, toff + j * 1024); o.x += k.x; o.y += k.y; o.z += k.z; o.w += k.w; }
+            if (SKIP) { const float4 k = kv[j]; o.x += k.x; o.y += k.y; o.z += k.z; o.w += k.w; }
             if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             slice_st(yr, toff + j * 1024, o);
         }
@@ -846,7 +857,7 @@ int launch_fused_fwd(const float* x, const float* gamma, const float* beta, cons
     static int resident = -1;
     std::lock_guard<std::mutex> order(gn_ctl().launch_mu);
     if (resident < 0) resident = resident_workgroups(kern);
-    const FusedLaunch L = fused_prepare(scratch, preset, B, C, S, FWD_MAXV4, resident, st);
+    const FusedLaunch L = fused_prepare(scratch, preset, B, C, S, SKIP ? FWDS_MAXV4 : FWD_MAXV4, resident, st);
     if (L.rc) return L.rc;
     hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), 0, st, x, gamma, beta, skip, y, mean_rstd, L.ctl, C,
                        S, L.g.cpg, L.g.wpc, L.g.nspans, L.g.v4_per_wg, eps);

@@ -50,6 +50,15 @@ def main():
         t2, tf = timeit(two_stage), timeit(fused)
         print(f"GN fwd B={B} C={Cc} {dims}: two-stage {t2:.3f} ms ({3 * mb / t2 * 1e3:.0f} GB/s of 3 passes)   "
               f"fused {tf:.3f} ms ({2 * mb / tf * 1e3:.0f} GB/s of 2 passes)")
+        sk = torch.randn_like(x)
+
+        def fused_skip():                                  # y = GroupNorm(x) + skip (the residual forms of the model): 2 reads + 1 write
+            cl = ops._gn_cluster(B, dev)
+            _lib.call("ecm_gn3d_fwd_p", p(x), p(gm), p(bt), p(sk), p(y), p(stats), p(scratch), C.c_longlong(nb), p(cl),
+                      C.c_longlong(cl.numel()), B, Cc, C.c_longlong(S), 0, C.c_float(1e-5), st)
+        ts = timeit(fused_skip)
+        print(f"GN fwd + skip (cluster kernel): {ts:.3f} ms ({3 * mb / ts * 1e3:.0f} GB/s of 3 passes)")
+        del sk
         xg = x.clone().requires_grad_()
         G = torch.randn_like(x)
         yy = ops.group_norm_act(xg, gm.requires_grad_(), bt.requires_grad_(), None, True)

@@ -461,6 +461,13 @@ __device__ __forceinline__ void cluster_restore(const FusedCtl& ctl, unsigned lo
     if (tid == 0) __hip_atomic_store(ctl.done + span, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef GN_PROFILE
+__device__ unsigned long long gn_prof[4];          // load phase, rendezvous, finishing pass, tickets (100 MHz ticks; sums over workgroups)
+#define GN_T(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&gn_prof[i], now_ - last_); last_ = now_; } } while (0)
+#else
+#define GN_T(i) do { } while (0)
+#endif
+
 template <bool RELU, bool SKIP>
 __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ skip,
@@ -479,6 +486,9 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
     if (tid == 0) { tick_s = tk.first(); if (tick_s >= tk.total) ticket_drawn(ctl, tk, tick_s); }
     __syncthreads();
     unsigned t = tick_s;
+#ifdef GN_PROFILE
+    unsigned long long last_ = __builtin_amdgcn_s_memrealtime();
+#endif
     while (t < tk.total) {
         const int span = (int)(t / (unsigned)cl), wic = (int)(t - (unsigned)span * (unsigned)cl);
         const int cig = wic / wpc, w = wic - cig * wpc;
@@ -508,6 +518,7 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
             q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
         }
         block_reduce2(s, q, sm);
+        GN_T(0);
         unsigned long long* sp = ctl.slots + (size_t)span * cl;
         if (tid == 0) slot_publish(sp + wic, s, q);
         // fixed-order total of the cl (<= 128) partials, identical in every workgroup of the cluster
@@ -515,6 +526,7 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         int got = 1;
         if (tid < cl) { float ps, pq; got = slot_collect(sp + tid, ps, pq, ctl.poll_ticks) ? 1 : 0; ds = (double)ps; dq = (double)pq; }
         const bool arrived = __syncthreads_and(got) != 0;
+        GN_T(1);
         // Draw the next ticket only now: a workgroup must never WAIT while it holds a ticket it has not published for
         // (the drawn ticket could belong to the very cluster it waits on).  From here on nothing blocks, and the draw's
         // latency hides under the finishing pass.
@@ -554,6 +566,10 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         if (tid == 0) tick_s = tnext;
         __syncthreads();          // tick_s; smd / sm are reused by the next span
         t = tick_s;
+        GN_T(2);
+#ifdef GN_PROFILE
+        if (tid == 0) atomicAdd(&gn_prof[3], 1ull);
+#endif
     }
 }
 
@@ -891,6 +907,14 @@ inline int gn_pending_error() {
 }
 
 }  // namespace
+
+#ifdef GN_PROFILE
+extern "C" int ecm_gn3d_profile(unsigned long long* out4, int reset) {
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(gn_prof), 4 * sizeof(unsigned long long)) != hipSuccess) return ECM_EINVAL;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(gn_prof), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 extern "C" int ecm_gn3d_cluster_mode(int mode) {
     GnControl& c = gn_ctl();

@@ -304,6 +304,18 @@ constexpr int FUSED_MAX_CPG = 8;
 constexpr int FWD_MAXV4 = ECM_GN_FWD_MAXV4;   // float4 per thread kept in registers; OCC workgroups per CU overlap one
 constexpr int BWD_MAXV4 = ECM_GN_BWD_MAXV4;   // cluster's wait with another's loads/stores
 constexpr int FWDS_MAXV4 = ECM_GN_FWDS_MAXV4;
+// Deferred stores.  A workgroup is idle for a quarter of every ticket: the rendezvous -- publish the partial sums, collect the
+// cluster's -- is two dependent trips through a busy memory pipeline, 5.6-10 us whatever the cluster size
+// (tools/gn_phase_profile.py).  Nothing can be LOADED for the next ticket meanwhile (the registers hold this one's slab), but
+// something can be STORED: the finishing pass parks the first STASH float4 per thread of its output in LDS (otherwise unused
+// by these kernels) instead of storing them, and the next ticket sends them out between its publish and its collect -- under
+// the wait.  (The last ticket of a workgroup flushes after its own finishing pass.)
+#ifndef ECM_GN_STASH_V4
+#define ECM_GN_STASH_V4 16        // x 256 threads x 16 B = 64 KB per workgroup, two workgroups per CU; 0 = off
+#endif
+constexpr int STASH_V4 = ECM_GN_STASH_V4;
+// (the backward variant that reads its mask from y AND writes the residual operand's gradient has no registers left for it)
+constexpr int bwd_stash_v4(int mask, int gskip) { return (mask == 1 && gskip == 1) ? 0 : (STASH_V4 < BWD_MAXV4 ? STASH_V4 : BWD_MAXV4); }
 
 // Slice access through buffer descriptors (base = first float4 of this workgroup's slice, num_records = slice bytes):
 // one 32-bit per-thread offset + immediates instead of a 64-bit address per register tile row, and float4s past the
@@ -418,11 +430,11 @@ inline FusedGeom fused_geom(int B, int C, long long S, int maxv4, int resident) 
 }
 
 template <class K>
-inline int resident_workgroups(K kern) {
+inline int resident_workgroups(K kern, int dynamic_lds = 0) {
     int dev = 0, cus = 0, per = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, THREADS, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, THREADS, (size_t)dynamic_lds) != hipSuccess) return 0;
     return cus * per;
 }
 
@@ -475,11 +487,19 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
                                                            FusedCtl ctl, int C, long long S, int cpg,
                                                            int wpc, int nspans, long long v4_per_wg, float eps) {
     constexpr int MAXV4 = SKIP ? FWDS_MAXV4 : FWD_MAXV4;
+    constexpr int NST = STASH_V4 < MAXV4 ? STASH_V4 : MAXV4;          // float4 per thread whose store is deferred through LDS
+    extern __shared__ __attribute__((aligned(16))) float4 stash[];     // [NST][THREADS]; a thread reads back only what it wrote
     __shared__ float sm[2 * THREADS / 64];
     __shared__ double smd[2 * THREADS / 64];
     __shared__ unsigned tick_s, last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = cpg * wpc;
+    bool parked = false;                                // the previous ticket's first NST float4 per thread wait in `stash`
+    __amdgpu_buffer_rsrc_t parked_r = slice_rsrc(y, 0);
+    // (Unconditional: switching it off at run time for launches of one or two tickets per workgroup -- where there is no later
+    // rendezvous to hide under and the trip through LDS costs 4-6 % -- made hipcc schedule BOTH paths worse: 22.0 ms of
+    // GroupNorm per step against 20.9 with the parking always on and 21.3 without it.)
+    constexpr bool stash_on = NST > 0;
     const long long nv4 = S >> 2;                       // < 2^31 (checked by the host): 32-bit indices within a channel
     const unsigned toff = (unsigned)(wave * MAXV4 * 64 + lane) * 16u;     // wave-contiguous rows of 64 float4 (1 KB)
     const Tickets tk{ctl.ticket, (unsigned)nspans * (unsigned)cl, gridDim.x, ctl.dynamic != 0};
@@ -521,6 +541,11 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
         GN_T(0);
         unsigned long long* sp = ctl.slots + (size_t)span * cl;
         if (tid == 0) slot_publish(sp + wic, s, q);
+        if (NST > 0 && parked) {                        // the previous ticket's parked output leaves under this ticket's rendezvous
+#pragma unroll
+            for (int j = 0; j < NST; ++j) slice_st(parked_r, toff + j * 1024, stash[j * THREADS + tid]);
+            parked = false;
+        }
         // fixed-order total of the cl (<= 128) partials, identical in every workgroup of the cluster
         double ds = 0.0, dq = 0.0;
         int got = 1;
@@ -561,8 +586,10 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
             o.z = __builtin_fmaf(o.z, a, sh); o.w = __builtin_fmaf(o.w, a, sh);
             if (SKIP) { const float4 k = kv[j]; o.x += k.x; o.y += k.y; o.z += k.z; o.w += k.w; }
             if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            slice_st(yr, toff + j * 1024, o);
+            if (j < NST && stash_on) stash[j * THREADS + tid] = o;
+            else slice_st(yr, toff + j * 1024, o);
         }
+        if (stash_on) { parked = true; parked_r = yr; }
         if (tid == 0) tick_s = tnext;
         __syncthreads();          // tick_s; smd / sm are reused by the next span
         t = tick_s;
@@ -570,6 +597,10 @@ __global__ __launch_bounds__(THREADS, ECM_GN_FWD_OCC) void gn_fused_fwd(const fl
 #ifdef GN_PROFILE
         if (tid == 0) atomicAdd(&gn_prof[3], 1ull);
 #endif
+    }
+    if (NST > 0 && parked) {                            // the last ticket's parked part
+#pragma unroll
+        for (int j = 0; j < NST; ++j) slice_st(parked_r, toff + j * 1024, stash[j * THREADS + tid]);
     }
 }
 
@@ -585,11 +616,16 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
                                                            long long S, int cpg, int wpc, int nspans,
                                                            long long v4_per_wg) {
     constexpr int MAXV4 = BWD_MAXV4;
+    constexpr int NST = bwd_stash_v4(MASK, GSKIP);                    // deferred stores of gx (see STASH_V4)
+    extern __shared__ __attribute__((aligned(16))) float4 stash[];
     __shared__ float sm[2 * THREADS / 64];
     __shared__ double chs[2 * FUSED_MAX_CPG];
     __shared__ unsigned tick_s, last_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = cpg * wpc;
+    bool parked = false;
+    __amdgpu_buffer_rsrc_t parked_r = slice_rsrc(gx, 0);
+    constexpr bool stash_on = NST > 0;                   // see gn_fused_fwd
     const long long nv4 = S >> 2;                       // < 2^31 (checked by the host): 32-bit indices within a channel
     const unsigned toff = (unsigned)(wave * MAXV4 * 64 + lane) * 16u;     // wave-contiguous rows of 64 float4 (1 KB)
     const Tickets tk{ctl.ticket, (unsigned)nspans * (unsigned)cl, gridDim.x, ctl.dynamic != 0};
@@ -641,6 +677,11 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
         block_reduce2(sg, sgx, sm);
         unsigned long long* sp = ctl.slots + (size_t)span * cl;
         if (tid == 0) slot_publish(sp + wic, sg, sgx);
+        if (NST > 0 && parked) {                        // the previous ticket's parked gx leaves under this ticket's rendezvous
+#pragma unroll
+            for (int j = 0; j < NST; ++j) slice_st(parked_r, toff + j * 1024, stash[j * THREADS + tid]);
+            parked = false;
+        }
         // per-channel totals (fixed order): wave k reduces the wpc partials of channels k, k+4, ...
         int got = 1;
         for (int cc = wave; cc < cpg; cc += THREADS / 64) {
@@ -680,12 +721,18 @@ __global__ __launch_bounds__(THREADS, ECM_GN_BWD_OCC) void gn_fused_bwd(const fl
             o.y = rstd * (gv[j].y * gm - k1 - xv[j].y * k2);
             o.z = rstd * (gv[j].z * gm - k1 - xv[j].z * k2);
             o.w = rstd * (gv[j].w * gm - k1 - xv[j].w * k2);
-            slice_st(orr, toff + j * 1024, o);
+            if (j < NST && stash_on) stash[j * THREADS + tid] = o;
+            else slice_st(orr, toff + j * 1024, o);
         }
+        if (stash_on) { parked = true; parked_r = orr; }
         if (tid == 0) tick_s = tnext;
         __syncthreads();          // tick_s; chs / sm are reused by the next span
         t = tick_s;
         if (last_s) cluster_restore(ctl, sp, span, cl, tid);
+    }
+    if (NST > 0 && parked) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) slice_st(parked_r, toff + j * 1024, stash[j * THREADS + tid]);
     }
 }
 
@@ -870,12 +917,15 @@ template <bool RELU, bool SKIP>
 int launch_fused_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, float* mean_rstd,
                      float* scratch, bool preset, int B, int C, long long S, float eps, hipStream_t st) {
     auto kern = gn_fused_fwd<RELU, SKIP>;
+    constexpr int MAXV4 = SKIP ? FWDS_MAXV4 : FWD_MAXV4;
+    constexpr int lds = (STASH_V4 < MAXV4 ? STASH_V4 : MAXV4) * THREADS * 16;
     static int resident = -1;
     std::lock_guard<std::mutex> order(gn_ctl().launch_mu);
-    if (resident < 0) resident = resident_workgroups(kern);
-    const FusedLaunch L = fused_prepare(scratch, preset, B, C, S, SKIP ? FWDS_MAXV4 : FWD_MAXV4, resident, st);
+    if (lds > 0 && ecm_allow_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return ECM_EINVAL;
+    if (resident < 0) resident = resident_workgroups(kern, lds);
+    const FusedLaunch L = fused_prepare(scratch, preset, B, C, S, MAXV4, resident, st);
     if (L.rc) return L.rc;
-    hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), 0, st, x, gamma, beta, skip, y, mean_rstd, L.ctl, C,
+    hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), lds, st, x, gamma, beta, skip, y, mean_rstd, L.ctl, C,
                        S, L.g.cpg, L.g.wpc, L.g.nspans, L.g.v4_per_wg, eps);
     const int rc = ECM_LAUNCH_RESULT();
     fused_launched(st);
@@ -887,12 +937,14 @@ int launch_fused_bwd(const float* x, const float* mean_rstd, const float* gamma,
                      const float* gy, float* gx, float* gskip, float* chan, float* scratch, bool preset, int B, int C, long long S,
                      hipStream_t st) {
     auto kern = gn_fused_bwd<MASK, GSKIP>;
+    constexpr int lds = bwd_stash_v4(MASK, GSKIP) * THREADS * 16;
     static int resident = -1;
     std::lock_guard<std::mutex> order(gn_ctl().launch_mu);
-    if (resident < 0) resident = resident_workgroups(kern);
+    if (lds > 0 && ecm_allow_lds(reinterpret_cast<const void*>(kern), lds) != hipSuccess) return ECM_EINVAL;
+    if (resident < 0) resident = resident_workgroups(kern, lds);
     const FusedLaunch L = fused_prepare(scratch, preset, B, C, S, BWD_MAXV4, resident, st);
     if (L.rc) return L.rc;
-    hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), 0, st, x, mean_rstd, gamma, beta, y, gy, gx, gskip,
+    hipLaunchKernelGGL(kern, dim3(L.g.grid), dim3(THREADS), lds, st, x, mean_rstd, gamma, beta, y, gy, gx, gskip,
                        chan, L.ctl, C, S, L.g.cpg, L.g.wpc, L.g.nspans, L.g.v4_per_wg);
     const int rc = ECM_LAUNCH_RESULT();
     fused_launched(st);

@@ -273,7 +273,9 @@ int ecm_costvol_class_weights_bwd(const float* gwP, const float* gwQ, float* gw,
  * stream at a time.  The kernels leave it in the preset state when they finish (the last member of a cluster restores the
  * cluster's slots, the last ticket draw the ticket counter), so no memset is issued per launch (ecm_gn3d_fwd / _bwd issue one:
  * 172 per cmfsm training step).  After an asynchronous time-out (ECM_EASYNC) the buffer must be preset again.  `scratch` as
- * for ecm_gn3d_fwd / _bwd (two-stage partials and the per-channel sums). */
+ * for ecm_gn3d_fwd / _bwd (two-stage partials and the per-channel sums).
+ * The one-pass kernels keep 64 KB of dynamic LDS per workgroup (two workgroups per CU): part of a slab's output waits there and
+ * is stored under the NEXT slab's exchange (csrc/gn3d.hip: STASH_V4).  y / gx must not alias any input of the call. */
 long long ecm_gn3d_cluster_bytes(int B);
 int ecm_gn3d_cluster_preset(void* cluster, long long cluster_bytes, void* stream);
 int ecm_gn3d_fwd_p(const float* x, const float* gamma, const float* beta, const float* skip, float* y,

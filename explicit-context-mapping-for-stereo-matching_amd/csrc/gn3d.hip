@@ -1002,6 +1002,7 @@ int gn_fwd_impl(const float* x, const float* gamma, const float* beta, const flo
                 void* scratch, long long scratch_bytes, float* cluster, bool preset, int B, int C, long long S, int relu,
                 float eps, void* stream) {
     if (C % GROUPS != 0 || (long long)B * C > 65535) return ECM_EUNSUP;
+    if (y == x || y == skip) return ECM_EINVAL;           // not in place: a span's pivot samples are read by all its workgroups
     if (scratch_bytes < ecm_gn3d_scratch_bytes(B, C, S)) return ECM_ESCRATCH;
     if (const int pe = gn_pending_error()) return pe;
     hipStream_t st = ecm_stream(stream);
@@ -1021,6 +1022,7 @@ int gn_bwd_impl(const float* x, const float* mean_rstd, const float* gamma, cons
                 long long scratch_bytes, float* cluster, bool preset, float* chan_fused, int B, int C, long long S, int relu,
                 void* stream) {
     if (C % GROUPS != 0 || (long long)B * C > 65535) return ECM_EUNSUP;
+    if (gx == x || gx == gy || gx == y || (gskip && (gskip == x || gskip == gy || gskip == gx))) return ECM_EINVAL;   // not in place
     if (scratch_bytes < ecm_gn3d_scratch_bytes(B, C, S)) return ECM_ESCRATCH;
     if (const int pe = gn_pending_error()) return pe;
     const int mask = !relu ? 0 : (y ? 1 : 2);

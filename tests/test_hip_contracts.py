@@ -85,3 +85,29 @@ def test_frame_the_architecture_cannot_take_fails_like_the_reference(ops):
     with torch.no_grad():                                      # the same model on a frame it can take
         out = model(r(1, 3, 256, 256), r(1, 3, 256, 256))
     assert all(torch.isfinite(o).all() for o in out)
+
+
+def test_groupnorm_refuses_in_place_calls(ops):
+    """The C ABI itself (a host that binds it directly): y == x or gx == gy would let one workgroup overwrite what another of the
+    same (sample, group) span still reads (the span's pivot samples; since round 4 also the output parked in LDS) -> ECM_EINVAL."""
+    import ctypes as C
+    lib, p = ops._lib, ops._p
+    B, Cc, S = 1, 32, 4 * 8 * 16
+    x, gm, bt = r(B, Cc, 4, 8, 16), r(Cc), r(Cc)
+    stats = torch.empty(B, 32, 2, device="cuda")
+    nb = lib.query("ecm_gn3d_scratch_bytes", B, Cc, C.c_longlong(S))
+    scratch = torch.empty(nb // 4 + 16, device="cuda")
+    keep = x.clone()
+    with pytest.raises(RuntimeError):
+        lib.call("ecm_gn3d_fwd", p(x), p(gm), p(bt), None, p(x), p(stats), p(scratch), C.c_longlong(nb), B, Cc, C.c_longlong(S), 1,
+                 C.c_float(1e-5), ops._stream())
+    y = torch.empty_like(x)
+    lib.call("ecm_gn3d_fwd", p(x), p(gm), p(bt), None, p(y), p(stats), p(scratch), C.c_longlong(nb), B, Cc, C.c_longlong(S), 1,
+             C.c_float(1e-5), ops._stream())
+    gy, gg, gb = r(B, Cc, 4, 8, 16), torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    with pytest.raises(RuntimeError):
+        lib.call("ecm_gn3d_bwd", p(x), p(stats), p(gm), p(bt), None, p(gy), p(gy), None, p(gg), p(gb), p(scratch), C.c_longlong(nb),
+                 B, Cc, C.c_longlong(S), 1, ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(x, keep)                                # nothing was launched on the refused calls
+    ops.check_async_errors()

@@ -584,6 +584,44 @@ def main():
             worst["conv3d_wgrad_stride2"] = {"kernel": "conv3d_wgrad_mfma (stride-2 layers: hourglass conv1/conv3 and the deconvs' weight gradients)",
                                              "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                              "frac": tf / PEAK_F32_MFMA_TFLOPS, "launches_timed": len(wg2), "avg_launch_ms": tot / len(wg2)}
+        # GroupNorm (17 % of the step, HBM-bound): algorithmic bytes = passes x tensor bytes -- forward x -> y (+ skip), backward
+        # x, gy -> gx (+ y where the ReLU mask comes from it, + gskip where it is written), statistics-only x
+        gn_bytes = gn_ms = 0.0
+        gn_n = 0
+        gn_big = [0.0, 0.0, 0]
+        for n_, evs in timers.items():
+            if not n_.startswith("ecm_gn3d") or n_ in ("ecm_gn3d_cluster_preset",):
+                continue
+            for s_, e_, a in evs:
+                if len(a) < 2 or not a.longs:
+                    continue
+                elems = float(a[0]) * a[1] * a.longs[-1]               # (B, C, ..., S last of the 64-bit arguments)
+                pt = a.ptrs
+                if "fwd" in n_:
+                    passes = 2 + (1 if len(pt) > 3 and pt[3] else 0)   # (x, gamma, beta, skip, y, ...)
+                elif "bwd" in n_:
+                    passes = 3 + (1 if len(pt) > 4 and pt[4] else 0) + (1 if len(pt) > 7 and pt[7] else 0)   # (.., y, gy, gx, gskip, ..)
+                elif "stats" in n_:
+                    passes = 1
+                else:
+                    passes = 2
+                t_ = s_.elapsed_time(e_)
+                gn_bytes += passes * elems * 4.0
+                gn_ms += t_
+                gn_n += 1
+                if elems == float(B) * 32 * Dl * h * w:                # the 849 MB maps of the 3-D stack at batch 4
+                    gn_big[0] += passes * elems * 4.0
+                    gn_big[1] += t_
+                    gn_big[2] += 1
+        if gn_n:
+            gbs = gn_bytes / (gn_ms * 1e-3) / 1e9
+            worst["groupnorm"] = {"kernel": "gn_fused_fwd / gn_fused_bwd (cluster kernels, one read + one write pass per operand) + gn_stats",
+                                  "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                  "launches_timed": gn_n, "ms_per_step": gn_ms / n_pass2,
+                                  "of_which_quarter_res_volumes": ({"achieved": gn_big[0] / (gn_big[1] * 1e-3) / 1e9,
+                                                                    "frac": gn_big[0] / (gn_big[1] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                                    "launches_timed": gn_big[2]} if gn_big[2] else None),
+                                  "yardstick": "ATen add (2 reads + 1 write, 849 MB operands) streams at 6.0 TB/s = 0.75 on this part (profiles/r04_stream_ceilings.txt)"}
         w2 = [(s, e, a) for n_ in ("ecm_conv_wino_fwd", "ecm_conv_wino_fwd_add") for (s, e, a) in timers.get(n_, []) if a[6] == 1]
         if w2:
             # 2-D Winograd F(2x2,3x3) (encoder + class convolutions, forward and data gradient; D = independent planes):

@@ -144,8 +144,10 @@ def disable_timers():
 
 
 class _Args(tuple):
-    """The integer arguments of a timed launch (what bench.py indexes); `.longs` holds the 64-bit ones (sizes) beside them."""
+    """The integer arguments of a timed launch (what bench.py indexes); `.longs` holds the 64-bit ones (sizes) beside them,
+    `.ptrs` one flag per pointer argument (False = NULL: an optional operand that was not passed)."""
     longs = ()
+    ptrs = ()
 
 
 def call(name: str, *args):
@@ -165,6 +167,7 @@ def call(name: str, *args):
         e.record()
         ints = _Args(a for a in args if isinstance(a, int))
         ints.longs = tuple(a.value for a in args if isinstance(a, C.c_longlong))
+        ints.ptrs = tuple(a is not None and bool(a.value) for a in args if a is None or isinstance(a, C.c_void_p))   # which optional operands were passed
         rec.append((s, e, ints))
     else:
         rc = fn(*args)
